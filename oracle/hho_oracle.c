@@ -1,0 +1,869 @@
+/*
+ * hho_oracle.c -- CPU restatement of ProtoN's per-cell HHO local operators.
+ * TEST INFRASTRUCTURE ONLY (see hho_oracle.h for the pinning status).
+ *
+ * Compile like the reference Release build (CMakeLists.txt:16): -O3 -mavx
+ * (no FMA contraction on that target, so plain mul/add rounding as in the
+ * reference's Eigen loops).
+ */
+#include "hho_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define IDX(i, j, ld) ((size_t)(i) + (size_t)(j) * (size_t)(ld))
+
+/* ------------------------------------------------------------------ */
+/* utils.hpp:62-111                                                    */
+/* ------------------------------------------------------------------ */
+hho_degrees hho_degree_info1(int degree)
+{
+    hho_degrees d = { degree, degree, degree + 1 };
+    return d;
+}
+
+hho_degrees hho_degree_info2(int cd, int fd, int *fell_back)
+{
+    hho_degrees d;
+    int c1 = fd > 0 && (cd == fd - 1 || cd == fd || cd == fd + 1);
+    int c2 = fd == 0 && (cd == fd || cd == fd + 1);
+    if (fell_back) *fell_back = !(c1 || c2);
+    if (c1 || c2) { d.cell_deg = cd; d.face_deg = fd; d.rec_deg = fd + 1; }
+    else          { d.cell_deg = fd; d.face_deg = fd; d.rec_deg = fd + 1; } /* utils.hpp:88-91 */
+    return d;
+}
+
+/* ------------------------------------------------------------------ */
+/* bases.hpp:27-50  square-and-multiply, same association order        */
+/* ------------------------------------------------------------------ */
+double hho_iexp_pow(double x, size_t n)
+{
+    if (n == 0) return 1;
+    double y = 1;
+    while (n > 1) {
+        if (n % 2 == 0) { x = x * x; n = n / 2; }
+        else            { y = x * y; x = x * x; n = (n - 1) / 2; }
+    }
+    return x * y;
+}
+
+/* ------------------------------------------------------------------ */
+/* quadratures.hpp:78-158                                              */
+/* ------------------------------------------------------------------ */
+int hho_gauss_legendre(int degree, double *nd, double *wt)
+{
+    int comp = degree;
+    if (degree % 2 == 0) comp = degree + 1;
+    int n = (comp + 1) / 2;
+    double qp, qw, a1, a2;
+    switch (n) {
+    case 1:
+        nd[0] = 0.0; wt[0] = 2.0; return 1;
+    case 2:
+        qp = 1.0 / sqrt(3.0); qw = 1.0;
+        nd[0] = -qp; wt[0] = qw; nd[1] = qp; wt[1] = qw; return 2;
+    case 3:
+        qp = sqrt(3.0 / 5.0); qw = 5.0 / 9.0;
+        nd[0] = -qp; wt[0] = qw; nd[1] = qp; wt[1] = qw;
+        nd[2] = 0.0; wt[2] = 8.0 / 9.0; return 3;
+    case 4:
+        a1 = 3.0 / 7.0; a2 = 2.0 * sqrt(6.0 / 5.0) / 7.0;
+        qp = sqrt(a1 - a2); qw = (18.0 + sqrt(30.0)) / 36.0;
+        nd[0] = -qp; wt[0] = qw; nd[1] = qp; wt[1] = qw;
+        qp = sqrt(a1 + a2); qw = (18.0 - sqrt(30.0)) / 36.0;
+        nd[2] = -qp; wt[2] = qw; nd[3] = qp; wt[3] = qw; return 4;
+    case 5:
+        nd[0] = 0.0; wt[0] = 128.0 / 225.0;
+        a1 = 5.0; a2 = 2.0 * sqrt(10.0 / 7.0);
+        qp = sqrt(a1 - a2) / 3.0; qw = (322 + 13.0 * sqrt(70.0)) / 900.0;
+        nd[1] = -qp; wt[1] = qw; nd[2] = qp; wt[2] = qw;
+        qp = sqrt(a1 + a2) / 3.0; qw = (322 - 13.0 * sqrt(70.0)) / 900.0;
+        nd[3] = -qp; wt[3] = qw; nd[4] = qp; wt[4] = qw; return 5;
+    default:
+        return -HHO_ERR_DEGREE; /* golub_welsch (quadratures.hpp:32-75) not restated */
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Dunavant rules, quadratures_dunavant.hpp:27-130.                    */
+/* Stored by symmetry orbit; expanded in the reference's row order.    */
+/*   kind 1: centroid (a,a,a)                                          */
+/*   kind 3: (a,b,b),(b,a,b),(b,b,a)                                   */
+/*   kind 6: (a,b,c),(a,c,b),(b,a,c),(b,c,a),(c,a,b),(c,b,a)           */
+/* Constants keep the reference's 15 printed digits.                   */
+/* ------------------------------------------------------------------ */
+typedef struct { int kind; double a, b, c, w; } dun_orbit;
+
+static const dun_orbit dun_r1[] = { {1, 0.333333333333333, 0, 0, 1.000000000000000} };
+static const dun_orbit dun_r2[] = { {3, 0.666666666666667, 0.166666666666667, 0, 0.333333333333333} };
+static const dun_orbit dun_r3[] = { {1, 0.333333333333333, 0, 0, -0.562500000000000},
+                                    {3, 0.600000000000000, 0.200000000000000, 0, 0.520833333333333} };
+static const dun_orbit dun_r4[] = { {3, 0.108103018168070, 0.445948490915965, 0, 0.223381589678011},
+                                    {3, 0.816847572980459, 0.091576213509771, 0, 0.109951743655322} };
+static const dun_orbit dun_r5[] = { {1, 0.333333333333333, 0, 0, 0.225000000000000},
+                                    {3, 0.059715871789770, 0.470142064105115, 0, 0.132394152788506},
+                                    {3, 0.797426985353087, 0.101286507323456, 0, 0.125939180544827} };
+static const dun_orbit dun_r6[] = { {3, 0.501426509658179, 0.249286745170910, 0, 0.116786275726379},
+                                    {3, 0.873821971016996, 0.063089014491502, 0, 0.050844906370207},
+                                    {6, 0.053145049844817, 0.310352451033784, 0.636502499121399, 0.082851075618374} };
+static const dun_orbit dun_r7[] = { {1, 0.333333333333333, 0, 0, -0.149570044467682},
+                                    {3, 0.479308067841920, 0.260345966079040, 0, 0.175615257433208},
+                                    {3, 0.869739794195568, 0.065130102902216, 0, 0.053347235608838},
+                                    {6, 0.048690315425316, 0.312865496004874, 0.638444188569810, 0.077113760890257} };
+static const dun_orbit dun_r8[] = { {1, 0.333333333333333, 0, 0, 0.144315607677787},
+                                    {3, 0.081414823414554, 0.459292588292723, 0, 0.095091634267285},
+                                    {3, 0.658861384496480, 0.170569307751760, 0, 0.103217370534718},
+                                    {3, 0.898905543365938, 0.050547228317031, 0, 0.032458497623198},
+                                    {6, 0.008394777409958, 0.263112829634638, 0.728492392955404, 0.027230314174435} };
+
+typedef struct { int n_orbits; const dun_orbit *orbits; } dun_rule;
+/* rules[] is 0-based in the reference: rules[i] == rule_{i+1}; rules[8] is the {0,NULL} sentinel
+ * (quadratures_dunavant.hpp:120-130).                                                            */
+static const dun_rule dun_rules[9] = {
+    {1, dun_r1}, {1, dun_r2}, {2, dun_r3}, {2, dun_r4}, {3, dun_r5},
+    {3, dun_r6}, {4, dun_r7}, {5, dun_r8}, {0, NULL}
+};
+
+static int dun_expand(int idx, double (*rows)[4])
+{
+    const dun_rule *r = &dun_rules[idx];
+    int n = 0;
+    for (int o = 0; o < r->n_orbits; o++) {
+        const dun_orbit *q = &r->orbits[o];
+        double a = q->a, b = q->b, c = q->c, w = q->w;
+        if (q->kind == 1) {
+            rows[n][0] = a; rows[n][1] = a; rows[n][2] = a; rows[n][3] = w; n++;
+        } else if (q->kind == 3) {
+            double t[3][3] = { {a, b, b}, {b, a, b}, {b, b, a} };
+            for (int k = 0; k < 3; k++) { rows[n][0] = t[k][0]; rows[n][1] = t[k][1]; rows[n][2] = t[k][2]; rows[n][3] = w; n++; }
+        } else {
+            double t[6][3] = { {a, b, c}, {a, c, b}, {b, a, c}, {b, c, a}, {c, a, b}, {c, b, a} };
+            for (int k = 0; k < 6; k++) { rows[n][0] = t[k][0]; rows[n][1] = t[k][1]; rows[n][2] = t[k][2]; rows[n][3] = w; n++; }
+        }
+    }
+    return n;
+}
+
+/* quadratures.hpp:238-271 */
+int hho_triangle_quadrature(const double p0[2], const double p1[2], const double p2[2],
+                            int deg, double *qx, double *qy, double *qw)
+{
+    if (deg == 0) deg = 1;
+    if (deg > 8) return -HHO_ERR_QUADRATURE;
+    double v0x = p1[0] - p0[0], v0y = p1[1] - p0[1];
+    double v1x = p2[0] - p0[0], v1y = p2[1] - p0[1];
+    double area = fabs((v0x * v1y - v0y * v1x) / 2.0);
+    double rows[16][4];
+    int n = dun_expand(deg, rows);              /* rules[deg] == rule_{deg+1}: the off-by-one */
+    for (int i = 0; i < n; i++) {
+        qx[i] = p0[0] * rows[i][0] + p1[0] * rows[i][1] + p2[0] * rows[i][2];
+        qy[i] = p0[1] * rows[i][0] + p1[1] * rows[i][1] + p2[1] * rows[i][2];
+        qw[i] = area * rows[i][3];
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* basic_geom.hpp                                                      */
+/* ------------------------------------------------------------------ */
+void hho_cell_barycenter(const double pts[8], double bar[2])   /* :247-278 */
+{
+    double rx = 0.0, ry = 0.0, den = 0.0;
+    double p0x = pts[0], p0y = pts[1];
+    for (int i = 2; i < 4; i++) {
+        double ax = pts[2 * (i - 1)] - p0x, ay = pts[2 * (i - 1) + 1] - p0y;
+        double bx = pts[2 * i] - p0x,       by = pts[2 * i + 1] - p0y;
+        double d = (ax * by - ay * bx) / 2.0;
+        rx = rx + (ax + bx) * d;
+        ry = ry + (ay + by) * d;
+        den += d;
+    }
+    bar[0] = p0x + rx / (den * 3);
+    bar[1] = p0y + ry / (den * 3);
+}
+
+double hho_cell_diameter(const double pts[8])                  /* :288-305 */
+{
+    double diam = 0.0;
+    for (int i = 0; i < 4; i++)
+        for (int j = i + 1; j < 4; j++) {
+            double dx = pts[2 * j] - pts[2 * i], dy = pts[2 * j + 1] - pts[2 * i + 1];
+            double d = sqrt(dx * dx + dy * dy);
+            diam = d > diam ? d : diam;
+        }
+    return diam;
+}
+
+double hho_cell_measure(const double pts[8])                   /* :317-334 */
+{
+    double acc = 0.0;
+    for (int i = 1; i < 3; i++) {
+        double ux = pts[2 * i] - pts[0],       uy = pts[2 * i + 1] - pts[1];
+        double vx = pts[2 * (i + 1)] - pts[0], vy = pts[2 * (i + 1) + 1] - pts[1];
+        acc += fabs(ux * vy - uy * vx) * 0.5;
+    }
+    return acc;
+}
+
+void hho_cell_normals(const double pts[8], double n[8])        /* :349-372 */
+{
+    for (int i = 0; i < 4; i++) {
+        int k = (i + 1) % 4;
+        double vx = pts[2 * k] - pts[2 * i], vy = pts[2 * k + 1] - pts[2 * i + 1];
+        double nx = vy, ny = -vx;
+        double nrm = sqrt(nx * nx + ny * ny);
+        n[2 * i] = nx / nrm; n[2 * i + 1] = ny / nrm;
+    }
+}
+
+void hho_cell_face_points(const double pts[8], const uint64_t ids[4], int f, double a[2], double b[2])
+{
+    int i0 = f, i1 = (f + 1) % 4;
+    if (ids[i0] > ids[i1]) { int t = i0; i0 = i1; i1 = t; }   /* basic_geom.hpp:202-203 */
+    a[0] = pts[2 * i0]; a[1] = pts[2 * i0 + 1];
+    b[0] = pts[2 * i1]; b[1] = pts[2 * i1 + 1];
+}
+
+/* ------------------------------------------------------------------ */
+/* quadratures.hpp:311-432                                             */
+/* ------------------------------------------------------------------ */
+static int tensor_cell_quadrature(const double p[8], int degree, double *qx, double *qy, double *qw)
+{
+    double nd[HHO_MAX_GAUSS], wt[HHO_MAX_GAUSS];
+    int n = hho_gauss_legendre(degree, nd, wt);
+    if (n < 0) return n;
+    int k = 0;
+    for (int j = 0; j < n; j++) {           /* outer: eta (:355) */
+        for (int i = 0; i < n; i++) {       /* inner: xi  (:357) */
+            double xi = nd[i], eta = nd[j];
+            double px = 0.25 * p[0] * (1 - xi) * (1 - eta) + 0.25 * p[2] * (1 + xi) * (1 - eta)
+                      + 0.25 * p[4] * (1 + xi) * (1 + eta) + 0.25 * p[6] * (1 - xi) * (1 + eta);
+            double py = 0.25 * p[1] * (1 - xi) * (1 - eta) + 0.25 * p[3] * (1 + xi) * (1 - eta)
+                      + 0.25 * p[5] * (1 + xi) * (1 + eta) + 0.25 * p[7] * (1 - xi) * (1 + eta);
+            double j11 = 0.25 * ((p[2] - p[0]) * (1 - eta) + (p[4] - p[6]) * (1 + eta));
+            double j12 = 0.25 * ((p[3] - p[1]) * (1 - eta) + (p[5] - p[7]) * (1 + eta));
+            double j21 = 0.25 * ((p[6] - p[0]) * (1 - xi) + (p[4] - p[2]) * (1 + xi));
+            double j22 = 0.25 * ((p[7] - p[1]) * (1 - xi) + (p[5] - p[3]) * (1 + xi));
+            double J = fabs(j11 * j22 - j12 * j21);
+            qx[k] = px; qy[k] = py; qw[k] = wt[i] * wt[j] * J;
+            k++;
+        }
+    }
+    return k;
+}
+
+static int fan_cell_quadrature(const double p[8], int degree, double *qx, double *qy, double *qw)
+{
+    double bar[2];
+    hho_cell_barycenter(p, bar);
+    int k = 0;
+    for (int i = 0; i < 4; i++) {           /* :390-399 */
+        const double *p0 = &p[2 * i], *p1 = &p[2 * ((i + 1) % 4)];
+        int n = hho_triangle_quadrature(p0, p1, bar, degree, qx + k, qy + k, qw + k);
+        if (n < 0) return n;
+        k += n;
+    }
+    return k;
+}
+
+int hho_cell_quadrature(const double pts[8], int quad_kind, int degree, double *qx, double *qy, double *qw)
+{
+    if (quad_kind == HHO_QUAD_TENSOR) return tensor_cell_quadrature(pts, degree, qx, qy, qw);
+    if (quad_kind == HHO_QUAD_FAN)    return fan_cell_quadrature(pts, degree, qx, qy, qw);
+    return -HHO_ERR_ARG;
+}
+
+int hho_face_quadrature(const double p0[2], const double p1[2], int degree, double *qx, double *qy, double *qw)
+{
+    double nd[HHO_MAX_GAUSS], wt[HHO_MAX_GAUSS];
+    int n = hho_gauss_legendre(degree, nd, wt);
+    if (n < 0) return n;
+    double sx = p1[0] - p0[0], sy = p1[1] - p0[1];
+    double meas = sqrt(sx * sx + sy * sy);
+    for (int i = 0; i < n; i++) {
+        double t = nd[i];
+        double a = 0.5 * (1 - t), b = 0.5 * (1 + t);
+        qx[i] = a * p0[0] + b * p1[0];
+        qy[i] = a * p0[1] + b * p1[1];
+        qw[i] = wt[i] * meas * 0.5;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* bases.hpp                                                           */
+/* ------------------------------------------------------------------ */
+void hho_cell_basis_eval(const double bar[2], double h, int degree, double x, double y, double *phi)
+{
+    double bx = (x - bar[0]) / (0.5 * h);
+    double by = (y - bar[1]) / (0.5 * h);
+    int pos = 0;
+    for (int k = 0; k <= degree; k++)
+        for (int i = 0; i <= k; i++)
+            phi[pos++] = hho_iexp_pow(bx, (size_t)(k - i)) * hho_iexp_pow(by, (size_t)i);
+}
+
+void hho_cell_basis_grad(const double bar[2], double h, int degree, double x, double y,
+                         double *gx, double *gy)
+{
+    double bx = (x - bar[0]) / (0.5 * h);
+    double by = (y - bar[1]) / (0.5 * h);
+    double ih = 2.0 / h;
+    int pos = 0;
+    for (int k = 0; k <= degree; k++)
+        for (int i = 0; i <= k; i++) {
+            size_t pow_x = (size_t)(k - i), pow_y = (size_t)i;
+            double px = hho_iexp_pow(bx, pow_x);
+            double py = hho_iexp_pow(by, pow_y);
+            double dx = (pow_x == 0) ? 0 : pow_x * ih * hho_iexp_pow(bx, pow_x - 1);
+            double dy = (pow_y == 0) ? 0 : pow_y * ih * hho_iexp_pow(by, pow_y - 1);
+            gx[pos] = dx * py;
+            gy[pos] = px * dy;
+            pos++;
+        }
+}
+
+void hho_face_basis_eval(const double p0[2], const double p1[2], int degree, double x, double y, double *phi)
+{
+    double barx = (p0[0] + p1[0]) / 2.0, bary = (p0[1] + p1[1]) / 2.0;   /* basic_geom.hpp:280-286 */
+    double dx = p1[0] - p0[0], dy = p1[1] - p0[1];
+    double fh = sqrt(dx * dx + dy * dy);                                   /* basic_geom.hpp:307-315 */
+    double basex = barx - p0[0], basey = bary - p0[1];                     /* bases.hpp:260-261 */
+    double tx = x - barx, ty = y - bary;
+    double dot = basex * tx + basey * ty;
+    double ep = 4.0 * dot / (fh * fh);
+    for (int i = 0; i <= degree; i++) phi[i] = hho_iexp_pow(ep, (size_t)i);
+}
+
+/* ------------------------------------------------------------------ */
+/* Eigen LLT semantics: unpivoted lower Cholesky, forward + backward   */
+/* ------------------------------------------------------------------ */
+int hho_llt_factor(double *A, int n)
+{
+    int bad = 0;
+    for (int j = 0; j < n; j++) {
+        double d = A[IDX(j, j, n)];
+        for (int k = 0; k < j; k++) d -= A[IDX(j, k, n)] * A[IDX(j, k, n)];
+        if (!(d > 0.0) && !bad) bad = j + 1;
+        d = sqrt(d);
+        A[IDX(j, j, n)] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = A[IDX(i, j, n)];
+            for (int k = 0; k < j; k++) s -= A[IDX(i, k, n)] * A[IDX(j, k, n)];
+            A[IDX(i, j, n)] = s / d;
+        }
+    }
+    for (int j = 1; j < n; j++)
+        for (int i = 0; i < j; i++) A[IDX(i, j, n)] = 0.0;
+    return bad;
+}
+
+void hho_llt_solve_inplace(const double *L, int n, double *B, int nrhs)
+{
+    for (int c = 0; c < nrhs; c++) {
+        double *b = B + (size_t)c * n;
+        for (int i = 0; i < n; i++) {
+            double s = b[i];
+            for (int k = 0; k < i; k++) s -= L[IDX(i, k, n)] * b[k];
+            b[i] = s / L[IDX(i, i, n)];
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            double s = b[i];
+            for (int k = i + 1; k < n; k++) s -= L[IDX(k, i, n)] * b[k];
+            b[i] = s / L[IDX(i, i, n)];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* hho.hpp:32-96                                                       */
+/* ------------------------------------------------------------------ */
+int hho_make_laplacian(const double pts[8], const uint64_t ids[4], hho_degrees di, int quad_kind,
+                       double *oper, double *data)
+{
+    int recdeg = di.rec_deg, celdeg = di.cell_deg, facdeg = di.face_deg;
+    if (recdeg > HHO_MAX_RECDEG || recdeg < 1 || celdeg < 0 || facdeg < 0) return HHO_ERR_DEGREE;
+    int rbs = hho_cell_basis_size(recdeg), cbs = hho_cell_basis_size(celdeg), fbs = hho_face_basis_size(facdeg);
+    int msize = cbs + 4 * fbs, nr = rbs - 1;
+
+    double bar[2]; hho_cell_barycenter(pts, bar);
+    double h = hho_cell_diameter(pts);
+
+    double stiff[HHO_MAX_RBS * HHO_MAX_RBS];
+    memset(stiff, 0, sizeof(double) * (size_t)rbs * rbs);
+    double gr_lhs[HHO_MAX_RBS * HHO_MAX_RBS];
+    double gr_rhs[HHO_MAX_RBS * HHO_MAX_MSIZE];
+    memset(gr_rhs, 0, sizeof(double) * (size_t)nr * msize);
+
+    double qx[HHO_MAX_CELL_QPS], qy[HHO_MAX_CELL_QPS], qw[HHO_MAX_CELL_QPS];
+    int nq = hho_cell_quadrature(pts, quad_kind, 2 * recdeg, qx, qy, qw);
+    if (nq < 0) return -nq;
+
+    double gx[HHO_MAX_RBS], gy[HHO_MAX_RBS], phi[HHO_MAX_RBS], fphi[HHO_MAX_FBS];
+    for (int q = 0; q < nq; q++) {                       /* :57-61 */
+        hho_cell_basis_grad(bar, h, recdeg, qx[q], qy[q], gx, gy);
+        for (int j = 0; j < rbs; j++)
+            for (int i = 0; i < rbs; i++)
+                stiff[IDX(i, j, rbs)] += (qw[q] * gx[i]) * gx[j] + (qw[q] * gy[i]) * gy[j];
+    }
+    for (int j = 0; j < nr; j++)                         /* :63 */
+        for (int i = 0; i < nr; i++) gr_lhs[IDX(i, j, nr)] = stiff[IDX(i + 1, j + 1, rbs)];
+    for (int j = 0; j < cbs; j++)                        /* :64 */
+        for (int i = 0; i < nr; i++) gr_rhs[IDX(i, j, nr)] = stiff[IDX(i + 1, j, rbs)];
+
+    double nrm[8]; hho_cell_normals(pts, nrm);
+    for (int f = 0; f < 4; f++) {                        /* :68-85 */
+        double fp0[2], fp1[2];
+        hho_cell_face_points(pts, ids, f, fp0, fp1);
+        double fx[HHO_MAX_GAUSS], fy[HHO_MAX_GAUSS], fw[HHO_MAX_GAUSS];
+        int nfq = hho_face_quadrature(fp0, fp1, 2 * facdeg, fx, fy, fw);
+        if (nfq < 0) return -nfq;
+        for (int q = 0; q < nfq; q++) {
+            hho_cell_basis_eval(bar, h, recdeg, fx[q], fy[q], phi);
+            hho_cell_basis_grad(bar, h, recdeg, fx[q], fy[q], gx, gy);
+            hho_face_basis_eval(fp0, fp1, facdeg, fx[q], fy[q], fphi);
+            for (int i = 0; i < nr; i++) {
+                double dn = gx[i + 1] * nrm[2 * f] + gy[i + 1] * nrm[2 * f + 1];
+                double wdn = fw[q] * dn;
+                for (int j = 0; j < fbs; j++) gr_rhs[IDX(i, cbs + f * fbs + j, nr)] += wdn * fphi[j];
+                for (int j = 0; j < cbs; j++) gr_rhs[IDX(i, j, nr)] -= wdn * phi[j];
+            }
+        }
+    }
+
+    int bad = hho_llt_factor(gr_lhs, nr);                /* :92 */
+    memcpy(oper, gr_rhs, sizeof(double) * (size_t)nr * msize);
+    hho_llt_solve_inplace(gr_lhs, nr, oper, msize);
+    for (int j = 0; j < msize; j++)                      /* :93 data = gr_rhs^T oper */
+        for (int i = 0; i < msize; i++) {
+            double s = 0.0;
+            for (int k = 0; k < nr; k++) s += gr_rhs[IDX(k, i, nr)] * oper[IDX(k, j, nr)];
+            data[IDX(i, j, msize)] = s;
+        }
+    return bad ? HHO_ERR_NOT_SPD : HHO_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* hho.hpp:99-148                                                      */
+/* ------------------------------------------------------------------ */
+int hho_make_naive_stabilization(const double pts[8], const uint64_t ids[4], hho_degrees di, double *data)
+{
+    int celdeg = di.cell_deg, facdeg = di.face_deg;
+    if (di.rec_deg > HHO_MAX_RECDEG || celdeg > HHO_MAX_RECDEG) return HHO_ERR_DEGREE;
+    int cbs = hho_cell_basis_size(celdeg), fbs = hho_face_basis_size(facdeg);
+    int msize = cbs + 4 * fbs;
+    memset(data, 0, sizeof(double) * (size_t)msize * msize);
+
+    double bar[2]; hho_cell_barycenter(pts, bar);
+    double hT = hho_cell_diameter(pts);
+    double h = hho_cell_measure(pts);                    /* :119 -- the cell AREA */
+    int bad = 0;
+
+    for (int f = 0; f < 4; f++) {
+        double fp0[2], fp1[2];
+        hho_cell_face_points(pts, ids, f, fp0, fp1);
+        double oper[HHO_MAX_FBS * HHO_MAX_MSIZE];
+        double mass[HHO_MAX_FBS * HHO_MAX_FBS], L[HHO_MAX_FBS * HHO_MAX_FBS];
+        double trace[HHO_MAX_FBS * HHO_MAX_RBS];
+        memset(oper, 0, sizeof(double) * (size_t)fbs * msize);
+        memset(mass, 0, sizeof(double) * (size_t)fbs * fbs);
+        memset(trace, 0, sizeof(double) * (size_t)fbs * cbs);
+        for (int i = 0; i < fbs; i++) oper[IDX(i, cbs + f * fbs + i, fbs)] = -1.0;   /* :130 */
+
+        double fx[HHO_MAX_GAUSS], fy[HHO_MAX_GAUSS], fw[HHO_MAX_GAUSS];
+        int nfq = hho_face_quadrature(fp0, fp1, 2 * facdeg, fx, fy, fw);
+        if (nfq < 0) return -nfq;
+        double cphi[HHO_MAX_RBS], fphi[HHO_MAX_FBS];
+        for (int q = 0; q < nfq; q++) {                  /* :133-140 */
+            hho_cell_basis_eval(bar, hT, celdeg, fx[q], fy[q], cphi);
+            hho_face_basis_eval(fp0, fp1, facdeg, fx[q], fy[q], fphi);
+            for (int j = 0; j < fbs; j++)
+                for (int i = 0; i < fbs; i++) mass[IDX(i, j, fbs)] += (fw[q] * fphi[i]) * fphi[j];
+            for (int j = 0; j < cbs; j++)
+                for (int i = 0; i < fbs; i++) trace[IDX(i, j, fbs)] += (fw[q] * fphi[i]) * cphi[j];
+        }
+        memcpy(L, mass, sizeof(double) * (size_t)fbs * fbs);
+        if (hho_llt_factor(L, fbs)) bad = 1;
+        hho_llt_solve_inplace(L, fbs, trace, cbs);       /* :142 */
+        memcpy(oper, trace, sizeof(double) * (size_t)fbs * cbs);
+
+        /* :144  data += ((oper^T * mass) * oper) * (1/h), left to right as Eigen evaluates it */
+        double otm[HHO_MAX_MSIZE * HHO_MAX_FBS];
+        for (int k = 0; k < fbs; k++)
+            for (int i = 0; i < msize; i++) {
+                double s = 0.0;
+                for (int l = 0; l < fbs; l++) s += oper[IDX(l, i, fbs)] * mass[IDX(l, k, fbs)];
+                otm[IDX(i, k, msize)] = s;
+            }
+        for (int j = 0; j < msize; j++)
+            for (int i = 0; i < msize; i++) {
+                double s = 0.0;
+                for (int k = 0; k < fbs; k++) s += otm[IDX(i, k, msize)] * oper[IDX(k, j, fbs)];
+                data[IDX(i, j, msize)] += s * (1. / h);
+            }
+    }
+    return bad ? HHO_ERR_NOT_SPD : HHO_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* hho.hpp:155-237                                                     */
+/* ------------------------------------------------------------------ */
+int hho_make_fancy_stabilization(const double pts[8], const uint64_t ids[4], hho_degrees di,
+                                 int quad_kind, const double *R, double *data)
+{
+    int recdeg = di.rec_deg, celdeg = di.cell_deg, facdeg = di.face_deg;
+    if (recdeg > HHO_MAX_RECDEG || recdeg < 1) return HHO_ERR_DEGREE;
+    int rbs = hho_cell_basis_size(recdeg), cbs = hho_cell_basis_size(celdeg), fbs = hho_face_basis_size(facdeg);
+    int msize = cbs + 4 * fbs, nr = rbs - 1;
+    int bad = 0;
+
+    double bar[2]; hho_cell_barycenter(pts, bar);
+    double hT = hho_cell_diameter(pts);
+
+    double mass[HHO_MAX_RBS * HHO_MAX_RBS];
+    memset(mass, 0, sizeof(double) * (size_t)rbs * rbs);
+    double qx[HHO_MAX_CELL_QPS], qy[HHO_MAX_CELL_QPS], qw[HHO_MAX_CELL_QPS];
+    int nq = hho_cell_quadrature(pts, quad_kind, 2 * recdeg, qx, qy, qw);
+    if (nq < 0) return -nq;
+    double phi[HHO_MAX_RBS], fphi[HHO_MAX_FBS];
+    for (int q = 0; q < nq; q++) {                       /* :175-179 */
+        hho_cell_basis_eval(bar, hT, recdeg, qx[q], qy[q], phi);
+        for (int j = 0; j < rbs; j++)
+            for (int i = 0; i < rbs; i++) mass[IDX(i, j, rbs)] += (qw[q] * phi[i]) * phi[j];
+    }
+
+    /* :184-190  proj1 = -M1^{-1} (M2 R) ; proj1[:, :cbs] += I */
+    double M1[HHO_MAX_RBS * HHO_MAX_RBS];
+    for (int j = 0; j < cbs; j++)
+        for (int i = 0; i < cbs; i++) M1[IDX(i, j, cbs)] = mass[IDX(i, j, rbs)];
+    double proj1[HHO_MAX_RBS * HHO_MAX_MSIZE];
+    for (int j = 0; j < msize; j++)
+        for (int i = 0; i < cbs; i++) {
+            double s = 0.0;
+            for (int k = 0; k < nr; k++) s += mass[IDX(i, 1 + k, rbs)] * R[IDX(k, j, nr)];
+            proj1[IDX(i, j, cbs)] = s;
+        }
+    if (hho_llt_factor(M1, cbs)) bad = 1;
+    hho_llt_solve_inplace(M1, cbs, proj1, msize);
+    for (size_t t = 0; t < (size_t)cbs * msize; t++) proj1[t] = -proj1[t];
+    for (int i = 0; i < cbs; i++) proj1[IDX(i, i, cbs)] += 1.0;
+
+    memset(data, 0, sizeof(double) * (size_t)msize * msize);
+
+    for (int f = 0; f < 4; f++) {                        /* :199-234 */
+        double h = hT;                                   /* :201 -- the cell DIAMETER */
+        double fp0[2], fp1[2];
+        hho_cell_face_points(pts, ids, f, fp0, fp1);
+        double fmass[HHO_MAX_FBS * HHO_MAX_FBS], L[HHO_MAX_FBS * HHO_MAX_FBS];
+        double ftrace[HHO_MAX_FBS * HHO_MAX_RBS];
+        memset(fmass, 0, sizeof(double) * (size_t)fbs * fbs);
+        memset(ftrace, 0, sizeof(double) * (size_t)fbs * rbs);
+        double fx[HHO_MAX_GAUSS], fy[HHO_MAX_GAUSS], fw[HHO_MAX_GAUSS];
+        int nfq = hho_face_quadrature(fp0, fp1, 2 * facdeg, fx, fy, fw);
+        if (nfq < 0) return -nfq;
+        for (int q = 0; q < nfq; q++) {                  /* :209-216 */
+            hho_face_basis_eval(fp0, fp1, facdeg, fx[q], fy[q], fphi);
+            hho_cell_basis_eval(bar, hT, recdeg, fx[q], fy[q], phi);
+            for (int j = 0; j < fbs; j++)
+                for (int i = 0; i < fbs; i++) fmass[IDX(i, j, fbs)] += (fw[q] * fphi[i]) * fphi[j];
+            for (int j = 0; j < rbs; j++)
+                for (int i = 0; i < fbs; i++) ftrace[IDX(i, j, fbs)] += (fw[q] * fphi[i]) * phi[j];
+        }
+        memcpy(L, fmass, sizeof(double) * (size_t)fbs * fbs);
+        if (hho_llt_factor(L, fbs)) bad = 1;
+
+        /* :222-226  proj2 = M_F^{-1} (MR1 R) ; proj2[:, face block] -= I */
+        double proj2[HHO_MAX_FBS * HHO_MAX_MSIZE], proj3[HHO_MAX_FBS * HHO_MAX_MSIZE];
+        for (int j = 0; j < msize; j++)
+            for (int i = 0; i < fbs; i++) {
+                double s = 0.0;
+                for (int k = 0; k < nr; k++) s += ftrace[IDX(i, 1 + k, fbs)] * R[IDX(k, j, nr)];
+                proj2[IDX(i, j, fbs)] = s;
+            }
+        hho_llt_solve_inplace(L, fbs, proj2, msize);
+        for (int i = 0; i < fbs; i++) proj2[IDX(i, cbs + f * fbs + i, fbs)] -= 1.0;
+        /* :229-230  proj3 = M_F^{-1} (MR2 proj1) */
+        for (int j = 0; j < msize; j++)
+            for (int i = 0; i < fbs; i++) {
+                double s = 0.0;
+                for (int k = 0; k < cbs; k++) s += ftrace[IDX(i, k, fbs)] * proj1[IDX(k, j, cbs)];
+                proj3[IDX(i, j, fbs)] = s;
+            }
+        hho_llt_solve_inplace(L, fbs, proj3, msize);
+        double BRF[HHO_MAX_FBS * HHO_MAX_MSIZE], BtM[HHO_MAX_MSIZE * HHO_MAX_FBS];
+        for (size_t t = 0; t < (size_t)fbs * msize; t++) BRF[t] = proj2[t] + proj3[t];
+        /* :233  data += ((BRF^T * M_F) * BRF) / h, left to right as Eigen evaluates it */
+        for (int k = 0; k < fbs; k++)
+            for (int i = 0; i < msize; i++) {
+                double s = 0.0;
+                for (int l = 0; l < fbs; l++) s += BRF[IDX(l, i, fbs)] * fmass[IDX(l, k, fbs)];
+                BtM[IDX(i, k, msize)] = s;
+            }
+        for (int j = 0; j < msize; j++)
+            for (int i = 0; i < msize; i++) {
+                double s = 0.0;
+                for (int k = 0; k < fbs; k++) s += BtM[IDX(i, k, msize)] * BRF[IDX(k, j, fbs)];
+                data[IDX(i, j, msize)] += s / h;
+            }
+    }
+    return bad ? HHO_ERR_NOT_SPD : HHO_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* utils.hpp:113-227                                                   */
+/* ------------------------------------------------------------------ */
+int hho_cell_mass_matrix(const double pts[8], int quad_kind, int degree, int di, double *mass)
+{
+    if (degree > HHO_MAX_RECDEG) return HHO_ERR_DEGREE;
+    int cbs = hho_cell_basis_size(degree);
+    memset(mass, 0, sizeof(double) * (size_t)cbs * cbs);
+    double bar[2]; hho_cell_barycenter(pts, bar);
+    double h = hho_cell_diameter(pts);
+    double qx[HHO_MAX_CELL_QPS], qy[HHO_MAX_CELL_QPS], qw[HHO_MAX_CELL_QPS], phi[HHO_MAX_RBS];
+    int nq = hho_cell_quadrature(pts, quad_kind, 2 * (degree + di), qx, qy, qw);
+    if (nq < 0) return -nq;
+    for (int q = 0; q < nq; q++) {
+        hho_cell_basis_eval(bar, h, degree, qx[q], qy[q], phi);
+        for (int j = 0; j < cbs; j++)
+            for (int i = 0; i < cbs; i++) mass[IDX(i, j, cbs)] += (qw[q] * phi[i]) * phi[j];
+    }
+    return HHO_OK;
+}
+
+int hho_face_mass_matrix(const double p0[2], const double p1[2], int degree, int di, double *mass)
+{
+    if (degree >= HHO_MAX_FBS) return HHO_ERR_DEGREE;
+    int fbs = hho_face_basis_size(degree);
+    memset(mass, 0, sizeof(double) * (size_t)fbs * fbs);
+    double fx[HHO_MAX_GAUSS], fy[HHO_MAX_GAUSS], fw[HHO_MAX_GAUSS], phi[HHO_MAX_FBS];
+    int n = hho_face_quadrature(p0, p1, 2 * (degree + di), fx, fy, fw);
+    if (n < 0) return -n;
+    for (int q = 0; q < n; q++) {
+        hho_face_basis_eval(p0, p1, degree, fx[q], fy[q], phi);
+        for (int j = 0; j < fbs; j++)
+            for (int i = 0; i < fbs; i++) mass[IDX(i, j, fbs)] += (fw[q] * phi[i]) * phi[j];
+    }
+    return HHO_OK;
+}
+
+int hho_cell_rhs(const double pts[8], int quad_kind, int degree, int di, hho_scalar_fn f, void *user, double *rhs)
+{
+    if (degree > HHO_MAX_RECDEG) return HHO_ERR_DEGREE;
+    int cbs = hho_cell_basis_size(degree);
+    memset(rhs, 0, sizeof(double) * (size_t)cbs);
+    double bar[2]; hho_cell_barycenter(pts, bar);
+    double h = hho_cell_diameter(pts);
+    double qx[HHO_MAX_CELL_QPS], qy[HHO_MAX_CELL_QPS], qw[HHO_MAX_CELL_QPS], phi[HHO_MAX_RBS];
+    int nq = hho_cell_quadrature(pts, quad_kind, 2 * (degree + di), qx, qy, qw);
+    if (nq < 0) return -nq;
+    for (int q = 0; q < nq; q++) {
+        hho_cell_basis_eval(bar, h, degree, qx[q], qy[q], phi);
+        double fv = f(qx[q], qy[q], user);
+        for (int i = 0; i < cbs; i++) rhs[i] += (qw[q] * phi[i]) * fv;
+    }
+    return HHO_OK;
+}
+
+int hho_face_rhs(const double p0[2], const double p1[2], int degree, int di, hho_scalar_fn f, void *user, double *rhs)
+{
+    if (degree >= HHO_MAX_FBS) return HHO_ERR_DEGREE;
+    int fbs = hho_face_basis_size(degree);
+    memset(rhs, 0, sizeof(double) * (size_t)fbs);
+    double fx[HHO_MAX_GAUSS], fy[HHO_MAX_GAUSS], fw[HHO_MAX_GAUSS], phi[HHO_MAX_FBS];
+    int n = hho_face_quadrature(p0, p1, 2 * (degree + di), fx, fy, fw);
+    if (n < 0) return -n;
+    for (int q = 0; q < n; q++) {
+        hho_face_basis_eval(p0, p1, degree, fx[q], fy[q], phi);
+        double fv = f(fx[q], fy[q], user);
+        for (int i = 0; i < fbs; i++) rhs[i] += (fw[q] * phi[i]) * fv;
+    }
+    return HHO_OK;
+}
+
+int hho_project_function(const double pts[8], const uint64_t ids[4], hho_degrees hdi, int quad_kind,
+                         hho_scalar_fn f, void *user, int di, double *out)
+{
+    int cbs = hho_cell_basis_size(hdi.cell_deg), fbs = hho_face_basis_size(hdi.face_deg);
+    double mm[HHO_MAX_RBS * HHO_MAX_RBS];
+    int st = hho_cell_mass_matrix(pts, quad_kind, hdi.cell_deg, di, mm);
+    if (st) return st;
+    st = hho_cell_rhs(pts, quad_kind, hdi.cell_deg, di, f, user, out);
+    if (st) return st;
+    int bad = hho_llt_factor(mm, cbs);
+    hho_llt_solve_inplace(mm, cbs, out, 1);
+    for (int i = 0; i < 4; i++) {
+        double p0[2], p1[2], fm[HHO_MAX_FBS * HHO_MAX_FBS];
+        hho_cell_face_points(pts, ids, i, p0, p1);
+        st = hho_face_mass_matrix(p0, p1, hdi.face_deg, di, fm);
+        if (st) return st;
+        st = hho_face_rhs(p0, p1, hdi.face_deg, di, f, user, out + cbs + i * fbs);
+        if (st) return st;
+        if (hho_llt_factor(fm, fbs)) bad = 1;
+        hho_llt_solve_inplace(fm, fbs, out + cbs + i * fbs, 1);
+    }
+    return bad ? HHO_ERR_NOT_SPD : HHO_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* Static condensation (not in the reference)           */
+/* ------------------------------------------------------------------ */
+int hho_static_condensation(const double *lc, const double *f, int cbs, int nf,
+                            double *S, double *g, double *rec)
+{
+    int ms = cbs + nf;
+    double ATT[HHO_MAX_RBS * HHO_MAX_RBS];
+    for (int j = 0; j < cbs; j++)
+        for (int i = 0; i < cbs; i++) ATT[IDX(i, j, cbs)] = lc[IDX(i, j, ms)];
+    /* rec = A_TT^{-1} [ f_T | -A_TF ] */
+    for (int i = 0; i < cbs; i++) rec[IDX(i, 0, cbs)] = f ? f[i] : 0.0;
+    for (int j = 0; j < nf; j++)
+        for (int i = 0; i < cbs; i++) rec[IDX(i, 1 + j, cbs)] = -lc[IDX(i, cbs + j, ms)];
+    int bad = hho_llt_factor(ATT, cbs);
+    hho_llt_solve_inplace(ATT, cbs, rec, nf + 1);
+    /* S = A_FF + A_FT rec[:,1:] ; g = -A_FT rec[:,0] */
+    for (int j = 0; j < nf; j++)
+        for (int i = 0; i < nf; i++) {
+            double s = lc[IDX(cbs + i, cbs + j, ms)];
+            for (int k = 0; k < cbs; k++) s += lc[IDX(cbs + i, k, ms)] * rec[IDX(k, 1 + j, cbs)];
+            S[IDX(i, j, nf)] = s;
+        }
+    for (int i = 0; i < nf; i++) {
+        double s = 0.0;
+        for (int k = 0; k < cbs; k++) s -= lc[IDX(cbs + i, k, ms)] * rec[IDX(k, 0, cbs)];
+        g[i] = s;
+    }
+    return bad ? HHO_ERR_NOT_SPD : HHO_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* basic_mesh.hpp:230-298                                              */
+/* ------------------------------------------------------------------ */
+size_t hho_mesh_num_points(const hho_mesh_params *p) { return (p->Nx + 1) * (p->Ny + 1); }
+size_t hho_mesh_num_cells(const hho_mesh_params *p)  { return p->Nx * p->Ny; }
+size_t hho_mesh_num_faces(const hho_mesh_params *p)  { return p->Nx * (p->Ny + 1) + p->Ny * (p->Nx + 1); }
+
+void hho_mesh_generate(const hho_mesh_params *p, double *points, uint64_t *cell_ptids)
+{
+    double hx = (p->max_x - p->min_x) / p->Nx;           /* :190-196 */
+    double hy = (p->max_y - p->min_y) / p->Ny;
+    size_t k = 0;
+    for (size_t j = 0; j < p->Ny + 1; j++)
+        for (size_t i = 0; i < p->Nx + 1; i++) {
+            points[2 * k]     = p->min_x + i * hx;
+            points[2 * k + 1] = p->min_y + j * hy;
+            k++;
+        }
+    /* cells are pushed row-major and then sorted lexicographically by ptids (:289); since
+     * ptids[0] is strictly increasing in push order the sort is the identity.              */
+    k = 0;
+    for (size_t j = 0; j < p->Ny; j++)
+        for (size_t i = 0; i < p->Nx; i++) {
+            uint64_t p0 = j * (p->Nx + 1) + i;
+            cell_ptids[4 * k + 0] = p0;
+            cell_ptids[4 * k + 1] = p0 + 1;
+            cell_ptids[4 * k + 2] = p0 + p->Nx + 2;
+            cell_ptids[4 * k + 3] = p0 + p->Nx + 1;
+            k++;
+        }
+}
+
+typedef struct { uint64_t lo, hi; uint8_t bnd; } face_rec;
+static int face_cmp(const void *a, const void *b)
+{
+    const face_rec *x = (const face_rec *)a, *y = (const face_rec *)b;
+    if (x->lo != y->lo) return x->lo < y->lo ? -1 : 1;
+    if (x->hi != y->hi) return x->hi < y->hi ? -1 : 1;
+    return 0;
+}
+
+void hho_mesh_generate_faces(const hho_mesh_params *p, uint64_t *faces, uint8_t *is_boundary)
+{
+    size_t nc = p->Nx * p->Ny;
+    face_rec *all = (face_rec *)malloc(sizeof(face_rec) * 4 * nc);
+    size_t k = 0;
+    for (size_t j = 0; j < p->Ny; j++)
+        for (size_t i = 0; i < p->Nx; i++) {             /* :253-286 */
+            uint64_t p0 = j * (p->Nx + 1) + i, p1 = p0 + 1, p2 = p0 + p->Nx + 2, p3 = p0 + p->Nx + 1;
+            face_rec f0 = { p0, p1, (uint8_t)(j == 0) };
+            face_rec f1 = { p1, p2, (uint8_t)(i == p->Nx - 1) };
+            face_rec f2 = { p3, p2, (uint8_t)(j == p->Ny - 1) };
+            face_rec f3 = { p0, p3, (uint8_t)(i == 0) };
+            all[k++] = f0; all[k++] = f1; all[k++] = f2; all[k++] = f3;
+        }
+    qsort(all, k, sizeof(face_rec), face_cmp);           /* :290 */
+    size_t n = 0;
+    for (size_t i = 0; i < k; i++) {                     /* :291 unique keeps the first of a run */
+        if (i > 0 && all[i].lo == all[i - 1].lo && all[i].hi == all[i - 1].hi) continue;
+        faces[2 * n] = all[i].lo; faces[2 * n + 1] = all[i].hi; is_boundary[n] = all[i].bnd; n++;
+    }
+    free(all);
+}
+
+size_t hho_mesh_face_id(const hho_mesh_params *p, size_t i, size_t j, int lf)
+{
+    size_t Nx = p->Nx, Ny = p->Ny;
+    /* faces sorted by (lo,hi): every point of row jj<Ny owns a horizontal (lo,lo+1) then a
+     * vertical (lo,lo+Nx+1) face, except the last point of the row (vertical only); the top
+     * row owns horizontals only.                                                          */
+    size_t row = 2 * Nx + 1;
+    switch (lf) {
+    case 0: /* bottom: horizontal at (i,j) */
+        return (j < Ny) ? j * row + 2 * i : Ny * row + i;
+    case 1: /* right: vertical at (i+1,j) */
+        return j * row + ((i + 1 < Nx) ? 2 * (i + 1) + 1 : 2 * Nx);
+    case 2: /* top: horizontal at (i,j+1) */
+        return (j + 1 < Ny) ? (j + 1) * row + 2 * i : Ny * row + i;
+    default: /* left: vertical at (i,j) */
+        return j * row + ((i < Nx) ? 2 * i + 1 : 2 * Nx);
+    }
+}
+
+int hho_mesh_face_is_boundary(const hho_mesh_params *p, size_t i, size_t j, int lf)
+{
+    switch (lf) {
+    case 0: return j == 0;
+    case 1: return i == p->Nx - 1;
+    case 2: return j == p->Ny - 1;
+    default: return i == 0;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Batched loop == the reference's per-cell "Matrix assembly" span     */
+/* (convergence_test.cpp:202-213 without the triplet push).            */
+/* ------------------------------------------------------------------ */
+int hho_local_ops_batch(const double *points, const uint64_t *cell_ptids, size_t first, size_t n,
+                        hho_degrees di, int quad_kind, int stab_kind,
+                        hho_scalar_fn f, void *user, int rhs_di,
+                        double *out_oper, double *out_data, double *out_stab, double *out_lc,
+                        double *out_rhs)
+{
+    int rbs = hho_cell_basis_size(di.rec_deg), cbs = hho_cell_basis_size(di.cell_deg);
+    int fbs = hho_face_basis_size(di.face_deg), msize = cbs + 4 * fbs, nr = rbs - 1;
+    size_t mm = (size_t)msize * msize, om = (size_t)nr * msize;
+    int worst = HHO_OK;
+    double oper[HHO_MAX_RBS * HHO_MAX_MSIZE], data[HHO_MAX_MSIZE * HHO_MAX_MSIZE], stab[HHO_MAX_MSIZE * HHO_MAX_MSIZE];
+    for (size_t c = 0; c < n; c++) {
+        const uint64_t *ids = cell_ptids + 4 * (first + c);
+        double pts[8];
+        for (int v = 0; v < 4; v++) { pts[2 * v] = points[2 * ids[v]]; pts[2 * v + 1] = points[2 * ids[v] + 1]; }
+        int st = hho_make_laplacian(pts, ids, di, quad_kind, oper, data);
+        if (st && st != HHO_ERR_NOT_SPD) return st;
+        if (st) worst = st;
+        if (stab_kind == HHO_STAB_FANCY)      st = hho_make_fancy_stabilization(pts, ids, di, quad_kind, oper, stab);
+        else if (stab_kind == HHO_STAB_NAIVE) st = hho_make_naive_stabilization(pts, ids, di, stab);
+        else { memset(stab, 0, sizeof(double) * mm); st = HHO_OK; }
+        if (st && st != HHO_ERR_NOT_SPD) return st;
+        if (st) worst = st;
+        if (out_oper) memcpy(out_oper + c * om, oper, sizeof(double) * om);
+        if (out_data) memcpy(out_data + c * mm, data, sizeof(double) * mm);
+        if (out_stab) memcpy(out_stab + c * mm, stab, sizeof(double) * mm);
+        if (out_lc) for (size_t t = 0; t < mm; t++) out_lc[c * mm + t] = data[t] + stab[t];
+        if (out_rhs && f) {
+            st = hho_cell_rhs(pts, quad_kind, di.cell_deg, rhs_di, f, user, out_rhs + c * (size_t)cbs);
+            if (st) return st;
+        }
+    }
+    return worst;
+}

@@ -1,0 +1,242 @@
+"""ctypes binding of the CPU oracle (oracle/libhho_oracle.so).
+
+Test infrastructure only: imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke() -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+
+QUAD_TENSOR, QUAD_FAN = 0, 1
+STAB_NONE, STAB_NAIVE, STAB_FANCY = 0, 1, 2
+
+
+class Degrees(C.Structure):
+    _fields_ = [("cell_deg", C.c_int), ("face_deg", C.c_int), ("rec_deg", C.c_int)]
+
+    @property
+    def rbs(self):
+        return (self.rec_deg + 2) * (self.rec_deg + 1) // 2
+
+    @property
+    def cbs(self):
+        return (self.cell_deg + 2) * (self.cell_deg + 1) // 2
+
+    @property
+    def fbs(self):
+        return self.face_deg + 1
+
+    @property
+    def msize(self):
+        return self.cbs + 4 * self.fbs
+
+
+class MeshParams(C.Structure):
+    _fields_ = [("Nx", C.c_size_t), ("Ny", C.c_size_t),
+                ("min_x", C.c_double), ("max_x", C.c_double),
+                ("min_y", C.c_double), ("max_y", C.c_double)]
+
+
+SCALAR_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_void_p)
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(ORACLE_DIR, "libhho_oracle.so")
+    src = os.path.join(ORACLE_DIR, "hho_oracle.c")
+    if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+        build()
+    L = C.CDLL(path)
+    dp = C.POINTER(C.c_double)
+    u64p = C.POINTER(C.c_uint64)
+    L.hho_degree_info1.restype = Degrees
+    L.hho_degree_info1.argtypes = [C.c_int]
+    L.hho_degree_info2.restype = Degrees
+    L.hho_degree_info2.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.hho_iexp_pow.restype = C.c_double
+    L.hho_iexp_pow.argtypes = [C.c_double, C.c_size_t]
+    L.hho_gauss_legendre.argtypes = [C.c_int, dp, dp]
+    L.hho_triangle_quadrature.argtypes = [dp, dp, dp, C.c_int, dp, dp, dp]
+    L.hho_cell_barycenter.argtypes = [dp, dp]
+    L.hho_cell_barycenter.restype = None
+    L.hho_cell_diameter.argtypes = [dp]
+    L.hho_cell_diameter.restype = C.c_double
+    L.hho_cell_measure.argtypes = [dp]
+    L.hho_cell_measure.restype = C.c_double
+    L.hho_cell_normals.argtypes = [dp, dp]
+    L.hho_cell_normals.restype = None
+    L.hho_cell_quadrature.argtypes = [dp, C.c_int, C.c_int, dp, dp, dp]
+    L.hho_face_quadrature.argtypes = [dp, dp, C.c_int, dp, dp, dp]
+    L.hho_cell_basis_eval.argtypes = [dp, C.c_double, C.c_int, C.c_double, C.c_double, dp]
+    L.hho_cell_basis_eval.restype = None
+    L.hho_cell_basis_grad.argtypes = [dp, C.c_double, C.c_int, C.c_double, C.c_double, dp, dp]
+    L.hho_cell_basis_grad.restype = None
+    L.hho_face_basis_eval.argtypes = [dp, dp, C.c_int, C.c_double, C.c_double, dp]
+    L.hho_face_basis_eval.restype = None
+    L.hho_cell_face_points.argtypes = [dp, u64p, C.c_int, dp, dp]
+    L.hho_cell_face_points.restype = None
+    L.hho_make_laplacian.argtypes = [dp, u64p, Degrees, C.c_int, dp, dp]
+    L.hho_make_naive_stabilization.argtypes = [dp, u64p, Degrees, dp]
+    L.hho_make_fancy_stabilization.argtypes = [dp, u64p, Degrees, C.c_int, dp, dp]
+    L.hho_cell_mass_matrix.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp]
+    L.hho_face_mass_matrix.argtypes = [dp, dp, C.c_int, C.c_int, dp]
+    L.hho_cell_rhs.argtypes = [dp, C.c_int, C.c_int, C.c_int, SCALAR_FN, C.c_void_p, dp]
+    L.hho_face_rhs.argtypes = [dp, dp, C.c_int, C.c_int, SCALAR_FN, C.c_void_p, dp]
+    L.hho_project_function.argtypes = [dp, u64p, Degrees, C.c_int, SCALAR_FN, C.c_void_p, C.c_int, dp]
+    L.hho_llt_factor.argtypes = [dp, C.c_int]
+    L.hho_llt_solve_inplace.argtypes = [dp, C.c_int, dp, C.c_int]
+    L.hho_llt_solve_inplace.restype = None
+    L.hho_static_condensation.argtypes = [dp, dp, C.c_int, C.c_int, dp, dp, dp]
+    mpp = C.POINTER(MeshParams)
+    for name in ("hho_mesh_num_points", "hho_mesh_num_cells", "hho_mesh_num_faces"):
+        getattr(L, name).restype = C.c_size_t
+        getattr(L, name).argtypes = [mpp]
+    L.hho_mesh_generate.argtypes = [mpp, dp, u64p]
+    L.hho_mesh_generate.restype = None
+    L.hho_mesh_generate_faces.argtypes = [mpp, u64p, C.POINTER(C.c_uint8)]
+    L.hho_mesh_generate_faces.restype = None
+    L.hho_mesh_face_id.argtypes = [mpp, C.c_size_t, C.c_size_t, C.c_int]
+    L.hho_mesh_face_id.restype = C.c_size_t
+    L.hho_mesh_face_is_boundary.argtypes = [mpp, C.c_size_t, C.c_size_t, C.c_int]
+    L.hho_local_ops_batch.argtypes = [dp, u64p, C.c_size_t, C.c_size_t, Degrees, C.c_int, C.c_int,
+                                      SCALAR_FN, C.c_void_p, C.c_int, dp, dp, dp, dp, dp]
+    _LIB = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _u64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def degrees(cd, fd):
+    fb = C.c_int(0)
+    d = lib().hho_degree_info2(cd, fd, C.byref(fb))
+    return d
+
+
+def _prep(pts, ids):
+    pts = np.ascontiguousarray(np.asarray(pts, dtype=np.float64).reshape(8))
+    ids = np.ascontiguousarray(np.asarray(ids, dtype=np.uint64).reshape(4))
+    return pts, ids
+
+
+def make_laplacian(pts, ids, di, quad=QUAD_TENSOR):
+    """-> (status, oper[(rbs-1) x msize], data[msize x msize]) as numpy (row,col) arrays."""
+    pts, ids = _prep(pts, ids)
+    nr, ms = di.rbs - 1, di.msize
+    oper = np.zeros((ms, nr))          # column-major storage == transposed C array
+    data = np.zeros((ms, ms))
+    st = lib().hho_make_laplacian(_dp(pts), _u64p(ids), di, quad, _dp(oper), _dp(data))
+    return st, oper.T.copy(), data.T.copy()
+
+
+def make_naive_stabilization(pts, ids, di):
+    pts, ids = _prep(pts, ids)
+    ms = di.msize
+    stab = np.zeros((ms, ms))
+    st = lib().hho_make_naive_stabilization(_dp(pts), _u64p(ids), di, _dp(stab))
+    return st, stab.T.copy()
+
+
+def make_fancy_stabilization(pts, ids, di, oper, quad=QUAD_TENSOR):
+    pts, ids = _prep(pts, ids)
+    ms = di.msize
+    stab = np.zeros((ms, ms))
+    R = np.ascontiguousarray(np.asarray(oper, dtype=np.float64).T)   # to column-major
+    st = lib().hho_make_fancy_stabilization(_dp(pts), _u64p(ids), di, quad, _dp(R), _dp(stab))
+    return st, stab.T.copy()
+
+
+def cell_rhs(pts, quad, degree, di, fn):
+    pts = np.ascontiguousarray(np.asarray(pts, dtype=np.float64).reshape(8))
+    n = (degree + 2) * (degree + 1) // 2
+    out = np.zeros(n)
+    cb = SCALAR_FN(lambda x, y, u: fn(x, y))
+    st = lib().hho_cell_rhs(_dp(pts), quad, degree, di, cb, None, _dp(out))
+    return st, out
+
+
+def project_function(pts, ids, di, fn, quad=QUAD_TENSOR, dinc=0):
+    pts, ids = _prep(pts, ids)
+    out = np.zeros(di.msize)
+    cb = SCALAR_FN(lambda x, y, u: fn(x, y))
+    st = lib().hho_project_function(_dp(pts), _u64p(ids), di, quad, cb, None, dinc, _dp(out))
+    return st, out
+
+
+def static_condensation(lc, f, cbs):
+    ms = lc.shape[0]
+    nf = ms - cbs
+    lcc = np.ascontiguousarray(lc.T)
+    f = np.ascontiguousarray(np.asarray(f, dtype=np.float64))
+    S = np.zeros((nf, nf))
+    g = np.zeros(nf)
+    rec = np.zeros((nf + 1, cbs))
+    st = lib().hho_static_condensation(_dp(lcc), _dp(f), cbs, nf, _dp(S), _dp(g), _dp(rec))
+    return st, S.T.copy(), g, rec.T.copy()
+
+
+def make_mesh(Nx, Ny, lo=(0.0, 0.0), hi=(1.0, 1.0)):
+    """-> (params, points[np,2], cell_ptids[nc,4] uint64)"""
+    mp = MeshParams(Nx, Ny, lo[0], hi[0], lo[1], hi[1])
+    L = lib()
+    npts, nc = L.hho_mesh_num_points(C.byref(mp)), L.hho_mesh_num_cells(C.byref(mp))
+    points = np.zeros((npts, 2))
+    ptids = np.zeros((nc, 4), dtype=np.uint64)
+    L.hho_mesh_generate(C.byref(mp), _dp(points), _u64p(ptids))
+    return mp, points, ptids
+
+
+def mesh_faces(mp):
+    L = lib()
+    nf = L.hho_mesh_num_faces(C.byref(mp))
+    faces = np.zeros((nf, 2), dtype=np.uint64)
+    bnd = np.zeros(nf, dtype=np.uint8)
+    L.hho_mesh_generate_faces(C.byref(mp), _u64p(faces), bnd.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return faces, bnd
+
+
+def local_ops_batch(points, ptids, di, quad, stab, first=0, n=None, fn=None, rhs_di=0,
+                    want=("lc",)):
+    """Run the oracle's batched per-cell loop; returns dict of cell-major numpy arrays
+    with matrices in (row, col) orientation."""
+    L = lib()
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    ptids = np.ascontiguousarray(ptids, dtype=np.uint64)
+    if n is None:
+        n = ptids.shape[0] - first
+    ms, nr, cbs = di.msize, di.rbs - 1, di.cbs
+    bufs = {}
+    ptr = {}
+    for key, shape in (("oper", (n, ms, nr)), ("data", (n, ms, ms)), ("stab", (n, ms, ms)),
+                       ("lc", (n, ms, ms))):
+        if key in want:
+            bufs[key] = np.zeros(shape)
+            ptr[key] = _dp(bufs[key])
+        else:
+            ptr[key] = None
+    cb = SCALAR_FN(lambda x, y, u: fn(x, y)) if fn is not None else C.cast(None, SCALAR_FN)
+    rhs = np.zeros((n, cbs)) if fn is not None else None
+    st = L.hho_local_ops_batch(_dp(points), _u64p(ptids), first, n, di, quad, stab, cb, None, rhs_di,
+                               ptr["oper"], ptr["data"], ptr["stab"], ptr["lc"],
+                               _dp(rhs) if rhs is not None else None)
+    out = {k: np.ascontiguousarray(np.swapaxes(v, 1, 2)) for k, v in bufs.items()}
+    if rhs is not None:
+        out["rhs"] = rhs
+    return st, out
