@@ -1,0 +1,156 @@
+/*
+ * proton_amd.h -- C ABI of the MI355X-native HHO local-operator assembly path.
+ *
+ * The reference (OmarDuran/ProtoN) is a header-only C++ template library with no
+ * FFI; its interface for this path is a set of per-cell function templates.  This
+ * ABI is the batched, device-side equivalent that a binding of those templates
+ * calls.  Each entry point cites the reference interface it replaces
+ * (paths relative to the reference root).  Plain pointers and sizes only; no
+ * C++/torch types; no exceptions cross this boundary (int status codes).
+ *
+ * Pointers named d_* are DEVICE pointers (hipMalloc'd or e.g. torch tensors'
+ * data_ptr()); everything else is host memory.  All matrices are column-major
+ * (Eigen's default, which the reference returns), batched cell-major:
+ * entry (row i, col j) of cell c lives at  base[c * rows*cols + j*rows + i].
+ *
+ * Threading: one context per device/stream; calls on a context are ordered by
+ * its HIP stream and are asynchronous with respect to the host unless stated.
+ */
+#ifndef PROTON_AMD_H
+#define PROTON_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_ABI_VERSION 1
+
+/* status codes (reference: C++ exceptions / silent NaNs) */
+enum {
+    PA_OK = 0,
+    PA_ERR_INVALID_ARG = 1,
+    PA_ERR_INVALID_DEGREE = 2,     /* hho_degree_info pair not instantiated                       */
+    PA_ERR_QUADRATURE = 3,         /* "Quadrature order too high" quadratures.hpp:245-246, incl. the
+                                      rules[8] hole of the fan quadrature (quadratures_dunavant.hpp:129) */
+    PA_ERR_HIP = 4,                /* a HIP runtime call failed; see pa_last_error()               */
+    PA_ERR_NO_MESH = 5,
+    PA_ERR_NOT_SPD = 6             /* some cell had a non-positive Cholesky pivot (Eigen LLT: silent) */
+};
+
+/* integrate() overloads: quadratures.hpp:311-375 (quad_mesh, tensor Gauss) and
+ * quadratures.hpp:377-402 (poly_mesh, 4-triangle fan + Dunavant). */
+enum { PA_QUAD_TENSOR = 0, PA_QUAD_FAN = 1 };
+/* stabilization choice: none / make_hho_naive_stabilization hho.hpp:99-148 /
+ * make_hho_fancy_stabilization hho.hpp:155-237 */
+enum { PA_STAB_NONE = 0, PA_STAB_NAIVE = 1, PA_STAB_FANCY = 2 };
+/* built-in source terms evaluated on the device (the reference passes a C++ lambda) */
+enum {
+    PA_FN_SAMPLED = 0,             /* values supplied per quadrature point by the caller            */
+    PA_FN_SIN_SIN_RHS = 1,         /* 2 pi^2 sin(pi x) sin(pi y)   convergence_test.cpp:100-102,
+                                      cuthho_square.cpp:846-848                                     */
+    PA_FN_SIN_SIN_SOL = 2,         /* sin(pi x) sin(pi y)          convergence_test.cpp:104-106     */
+    PA_FN_OBSTACLE_RHS = 3,        /* obstacle.cpp:67-74  (r0 = 0.7)                                */
+    PA_FN_OBSTACLE_SOL = 4,        /* obstacle.cpp:76-81                                            */
+    PA_FN_ONE = 5
+};
+
+typedef struct pa_context pa_context;
+
+/* hho_degree_info (utils.hpp:62-111) as plain ints */
+typedef struct { int32_t cell_deg, face_deg, rec_deg; } pa_degree_info;
+/* hho_degree_info(size_t) utils.hpp:71-73 */
+pa_degree_info pa_degree_info_equal(int degree);
+/* hho_degree_info(size_t cd, size_t fd) utils.hpp:75-95; *fell_back (may be NULL) is set
+ * when the pair is invalid and the reference "reverts to equal-order" */
+pa_degree_info pa_degree_info_make(int cd, int fd, int *fell_back);
+
+/* sizes: cell_basis::size bases.hpp:191-194, face_basis::size bases.hpp:287-290 */
+typedef struct {
+    int32_t rbs, cbs, fbs, msize;      /* msize = cbs + 4 fbs                                   */
+    int32_t oper_rows;                 /* rbs - 1 (hho.hpp:52-53)                               */
+    int32_t cell_qps, face_qps;        /* points of integrate(cell, 2 recdeg) / (face, 2 facdeg) */
+} pa_sizes;
+int pa_sizes_for(pa_degree_info di, int quad_kind, pa_sizes *out);
+
+/* ---- context ------------------------------------------------------------------------ */
+/* `stream` is a hipStream_t (NULL = the context creates and owns one). */
+int pa_context_create(int device, void *stream, pa_context **out);
+int pa_context_destroy(pa_context *ctx);
+int pa_context_synchronize(pa_context *ctx);
+const char *pa_last_error(pa_context *ctx);      /* text of the last HIP failure, "" if none  */
+int pa_abi_version(void);
+
+/* device-memory helpers so a non-torch host (the C++ header, a cgo/JNI caller) needs no HIP */
+int pa_malloc(pa_context *ctx, size_t bytes, void **d_out);
+int pa_free(pa_context *ctx, void *d_ptr);
+int pa_memcpy_h2d(pa_context *ctx, void *d_dst, const void *src, size_t bytes);   /* synchronous */
+int pa_memcpy_d2h(pa_context *ctx, void *dst, const void *d_src, size_t bytes);   /* synchronous */
+int pa_memset(pa_context *ctx, void *d_dst, int value, size_t bytes);
+
+/* ---- mesh ----------------------------------------------------------------------------
+ * Replaces the mesh<T,4,...> storage the kernels consume: msh.points (basic_mesh.hpp:222)
+ * and cell.ptids (basic_mesh.hpp:51).  points: np x 2 doubles (x,y), cell_ptids: nc x 4
+ * uint32 in the reference's CCW order.  The arrays are copied to the device. */
+int pa_mesh_upload(pa_context *ctx, const double *points, size_t npoints,
+                   const uint32_t *cell_ptids, size_t ncells);
+/* Same, but the arrays already live on the device and are borrowed (not copied, not freed). */
+int pa_mesh_attach_device(pa_context *ctx, const double *d_points, size_t npoints,
+                          const uint32_t *d_cell_ptids, size_t ncells);
+/* Structured generator mesh_impl<T,4>(mesh_init_params) basic_mesh.hpp:230-298, built on
+ * the device: points (min + i*h), cells {p, p+1, p+Nx+2, p+Nx+1}, cell id = j*Nx + i.
+ * row_begin/row_end select the block of cell rows [row_begin,row_end) this context owns
+ * (multi-GPU partition); cell index 0 of the context is global cell row_begin*Nx. */
+int pa_mesh_generate(pa_context *ctx, size_t Nx, size_t Ny,
+                     double min_x, double max_x, double min_y, double max_y,
+                     size_t row_begin, size_t row_end);
+int pa_mesh_counts(pa_context *ctx, size_t *npoints, size_t *ncells);
+
+/* ---- the hot path --------------------------------------------------------------------
+ * For cells [first, first+n) of the uploaded mesh computes, per cell,
+ *   (oper, data) = make_hho_laplacian(msh, cl, di)                 hho.hpp:32-96
+ *   stab         = make_hho_{naive,fancy}_stabilization(...)       hho.hpp:99-148 / 155-237
+ *   lc           = data + stab                                     convergence_test.cpp:212
+ * Any of the d_* outputs may be NULL (not written).  Shapes per cell:
+ *   d_oper (rbs-1) x msize, d_data/d_stab/d_lc msize x msize, d_info one int32
+ *   (0, or 1+index of the first non-positive Cholesky pivot: 100+ for the cell-mass
+ *   factorization of the fancy stabilization).
+ * Asynchronous on the context's stream. */
+int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind,
+                       size_t first, size_t n,
+                       double *d_oper, double *d_data, double *d_stab, double *d_lc,
+                       int32_t *d_info);
+
+/* make_rhs(msh, cl, degree, f, di) utils.hpp:153-174 for every cell in [first, first+n):
+ * d_rhs[c][cbs(degree)].  fn = PA_FN_*; with PA_FN_SAMPLED d_fvals holds f at the
+ * quadrature points of integrate(cell, 2*(degree+dinc)), n x nqp doubles in the
+ * reference's point order (pa_cell_quadrature_points returns the points). */
+int pa_cell_rhs_batch(pa_context *ctx, int degree, int dinc, int quad_kind, int fn,
+                      const double *d_fvals, size_t first, size_t n, double *d_rhs);
+/* integrate(msh, cl, degree) quadratures.hpp:311-402: d_xyw[c][nqp][3] = (x, y, weight) */
+int pa_cell_quadrature_points(pa_context *ctx, int degree, int quad_kind,
+                              size_t first, size_t n, double *d_xyw, int32_t *nqp_out);
+
+/* Static condensation of the cell unknowns (the reference has none):
+ *   S = A_FF - A_FT A_TT^-1 A_TF,  g = -A_FT A_TT^-1 f_T,
+ *   rec = [ A_TT^-1 f_T | -A_TT^-1 A_TF ]   (cbs x (1 + 4 fbs)),  u_T = rec[:,0] + rec[:,1:] u_F.
+ * d_lc: n x msize^2, d_rhs: n x cbs (may be NULL = 0).  Outputs may be NULL. */
+int pa_static_condensation_batch(pa_context *ctx, pa_degree_info di, size_t n,
+                                 const double *d_lc, const double *d_rhs,
+                                 double *d_S, double *d_g, double *d_rec, int32_t *d_info);
+
+/* occupancy / launch facts of the dominant kernel for the roofline bookkeeping */
+typedef struct {
+    int32_t lanes_per_cell, cells_per_block, block_threads, lds_bytes_per_block;
+    int32_t grid_blocks;
+    const char *kernel_name;
+} pa_launch_info;
+int pa_local_ops_launch_info(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind,
+                             size_t n, pa_launch_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

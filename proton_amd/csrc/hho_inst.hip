@@ -1,0 +1,34 @@
+// hho_inst.hip -- one translation unit per (cell degree, face degree, quadrature kind):
+// compiled with -DPA_CD= -DPA_FD= -DPA_QUAD= -DPA_GMIN= (see pa_configs.def, _build.py).
+#include "hho_launch.hpp"
+
+#if !defined(PA_CD) || !defined(PA_FD) || !defined(PA_QUAD) || !defined(PA_GMIN)
+#error "compile with -DPA_CD -DPA_FD -DPA_QUAD -DPA_GMIN"
+#endif
+
+#define PA_STR2(x) #x
+#define PA_STR(x) PA_STR2(x)
+#define PA_CAT5(a, b, c, d, e) pa_entries_##a##_##b##_##c
+#define PA_ENTRY(STAB, G)                                                                          \
+    {PA_CD, PA_FD, PA_QUAD, STAB, G, &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>>, \
+     (const void *)&pa::hho_local_ops_kernel<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>>,              \
+     (int)(pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::LDS_DOUBLES * sizeof(double)),                  \
+     "hho_local_ops<cd=" PA_STR(PA_CD) ",fd=" PA_STR(PA_FD) ",quad=" PA_STR(PA_QUAD) ",stab=" #STAB ",G=" #G ">"}
+#define PA_ENTRIES_G(G) PA_ENTRY(0, G), PA_ENTRY(1, G), PA_ENTRY(2, G)
+
+static const pa::KernelEntry k_entries[] = {
+#if PA_GMIN <= 16
+    PA_ENTRIES_G(16),
+#endif
+#if PA_GMIN <= 32
+    PA_ENTRIES_G(32),
+#endif
+    PA_ENTRIES_G(64)};
+
+#define PA_FN2(cd, fd, q) pa_entries_##cd##_##fd##_##q
+#define PA_FN(cd, fd, q) PA_FN2(cd, fd, q)
+extern "C" const pa::KernelEntry *PA_FN(PA_CD, PA_FD, PA_QUAD)(int *count)
+{
+    *count = (int)(sizeof(k_entries) / sizeof(k_entries[0]));
+    return k_entries;
+}

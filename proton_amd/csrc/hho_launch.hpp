@@ -1,0 +1,25 @@
+// hho_launch.hpp -- host-side registry of the instantiated local-operator kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hho_device.hpp"
+
+namespace pa {
+
+typedef hipError_t (*local_ops_launcher)(const LocalOpsArgs &, int grid, hipStream_t);
+
+struct KernelEntry {
+    int cd, fd, quad, stab, lanes_per_cell;
+    local_ops_launcher launch;
+    const void *func;          // for the occupancy query
+    int lds_bytes;
+    const char *name;
+};
+
+template <class C>
+hipError_t launch_local_ops(const LocalOpsArgs &a, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(hho_local_ops_kernel<C>, dim3(grid), dim3(64), C::LDS_DOUBLES * sizeof(double), s, a);
+    return hipGetLastError();
+}
+
+}  // namespace pa

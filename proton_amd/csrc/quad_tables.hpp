@@ -1,0 +1,102 @@
+// quad_tables.hpp -- host-side construction of the quadrature tables the kernels read
+// from __constant__ memory.
+//   Gauss-Legendre: closed forms and emission order of gauss_legendre()
+//                   (src/core/core_bits/quadratures.hpp:78-158); rules with more than five
+//                   nodes (golub_welsch, :32-75) are never requested for k <= 3.
+//   Dunavant:       the rules triangle_quadrature() indexes (quadratures.hpp:238-271,
+//                   quadratures_dunavant.hpp:27-130), kept with the reference's 15 printed
+//                   digits, expanded from their symmetry orbits in the reference's row order.
+#pragma once
+
+#include <cmath>
+#include <cstring>
+
+#include "hho_device.hpp"
+
+namespace pa {
+
+inline void fill_gauss(QuadTables &t)
+{
+    std::memset(t.gauss_x, 0, sizeof(t.gauss_x));
+    std::memset(t.gauss_w, 0, sizeof(t.gauss_w));
+    // n = 1
+    t.gauss_x[1][0] = 0.0; t.gauss_w[1][0] = 2.0;
+    // n = 2
+    {
+        const double q = 1.0 / std::sqrt(3.0);
+        t.gauss_x[2][0] = -q; t.gauss_x[2][1] = q;
+        t.gauss_w[2][0] = 1.0; t.gauss_w[2][1] = 1.0;
+    }
+    // n = 3: -q, +q, 0
+    {
+        const double q = std::sqrt(3.0 / 5.0);
+        t.gauss_x[3][0] = -q; t.gauss_x[3][1] = q; t.gauss_x[3][2] = 0.0;
+        t.gauss_w[3][0] = 5.0 / 9.0; t.gauss_w[3][1] = 5.0 / 9.0; t.gauss_w[3][2] = 8.0 / 9.0;
+    }
+    // n = 4: inner pair then outer pair
+    {
+        const double a1 = 3.0 / 7.0, a2 = 2.0 * std::sqrt(6.0 / 5.0) / 7.0;
+        const double qi = std::sqrt(a1 - a2), wi = (18.0 + std::sqrt(30.0)) / 36.0;
+        const double qo = std::sqrt(a1 + a2), wo = (18.0 - std::sqrt(30.0)) / 36.0;
+        t.gauss_x[4][0] = -qi; t.gauss_x[4][1] = qi; t.gauss_x[4][2] = -qo; t.gauss_x[4][3] = qo;
+        t.gauss_w[4][0] = wi; t.gauss_w[4][1] = wi; t.gauss_w[4][2] = wo; t.gauss_w[4][3] = wo;
+    }
+    // n = 5: 0, inner pair, outer pair
+    {
+        const double a1 = 5.0, a2 = 2.0 * std::sqrt(10.0 / 7.0);
+        const double qi = std::sqrt(a1 - a2) / 3.0, wi = (322 + 13.0 * std::sqrt(70.0)) / 900.0;
+        const double qo = std::sqrt(a1 + a2) / 3.0, wo = (322 - 13.0 * std::sqrt(70.0)) / 900.0;
+        t.gauss_x[5][0] = 0.0; t.gauss_w[5][0] = 128.0 / 225.0;
+        t.gauss_x[5][1] = -qi; t.gauss_x[5][2] = qi; t.gauss_w[5][1] = wi; t.gauss_w[5][2] = wi;
+        t.gauss_x[5][3] = -qo; t.gauss_x[5][4] = qo; t.gauss_w[5][3] = wo; t.gauss_w[5][4] = wo;
+    }
+}
+
+struct DunavantOrbit { int mult; double a, b, c, w; };   // mult 1: (a,a,a); 3: one a two b; 6: all distinct
+
+inline void fill_dunavant(QuadTables &t)
+{
+    static const DunavantOrbit r1[] = {{1, 0.333333333333333, 0, 0, 1.000000000000000}};
+    static const DunavantOrbit r2[] = {{3, 0.666666666666667, 0.166666666666667, 0, 0.333333333333333}};
+    static const DunavantOrbit r3[] = {{1, 0.333333333333333, 0, 0, -0.562500000000000},
+                                       {3, 0.600000000000000, 0.200000000000000, 0, 0.520833333333333}};
+    static const DunavantOrbit r4[] = {{3, 0.108103018168070, 0.445948490915965, 0, 0.223381589678011},
+                                       {3, 0.816847572980459, 0.091576213509771, 0, 0.109951743655322}};
+    static const DunavantOrbit r5[] = {{1, 0.333333333333333, 0, 0, 0.225000000000000},
+                                       {3, 0.059715871789770, 0.470142064105115, 0, 0.132394152788506},
+                                       {3, 0.797426985353087, 0.101286507323456, 0, 0.125939180544827}};
+    static const DunavantOrbit r6[] = {{3, 0.501426509658179, 0.249286745170910, 0, 0.116786275726379},
+                                       {3, 0.873821971016996, 0.063089014491502, 0, 0.050844906370207},
+                                       {6, 0.053145049844817, 0.310352451033784, 0.636502499121399, 0.082851075618374}};
+    static const DunavantOrbit r7[] = {{1, 0.333333333333333, 0, 0, -0.149570044467682},
+                                       {3, 0.479308067841920, 0.260345966079040, 0, 0.175615257433208},
+                                       {3, 0.869739794195568, 0.065130102902216, 0, 0.053347235608838},
+                                       {6, 0.048690315425316, 0.312865496004874, 0.638444188569810, 0.077113760890257}};
+    static const DunavantOrbit r8[] = {{1, 0.333333333333333, 0, 0, 0.144315607677787},
+                                       {3, 0.081414823414554, 0.459292588292723, 0, 0.095091634267285},
+                                       {3, 0.658861384496480, 0.170569307751760, 0, 0.103217370534718},
+                                       {3, 0.898905543365938, 0.050547228317031, 0, 0.032458497623198},
+                                       {6, 0.008394777409958, 0.263112829634638, 0.728492392955404, 0.027230314174435}};
+    static const struct { int n; const DunavantOrbit *o; } rules[9] = {
+        {1, r1}, {1, r2}, {2, r3}, {2, r4}, {3, r5}, {3, r6}, {4, r7}, {5, r8}, {0, nullptr}};   // [8]: the empty sentinel
+
+    std::memset(t.dun, 0, sizeof(t.dun));
+    for (int r = 0; r < 9; ++r) {
+        int n = 0;
+        auto put = [&](double l0, double l1, double l2, double w) {
+            t.dun[r][n][0] = l0; t.dun[r][n][1] = l1; t.dun[r][n][2] = l2; t.dun[r][n][3] = w; ++n;
+        };
+        for (int k = 0; k < rules[r].n; ++k) {
+            const DunavantOrbit &q = rules[r].o[k];
+            if (q.mult == 1) put(q.a, q.a, q.a, q.w);
+            else if (q.mult == 3) { put(q.a, q.b, q.b, q.w); put(q.b, q.a, q.b, q.w); put(q.b, q.b, q.a, q.w); }
+            else {
+                put(q.a, q.b, q.c, q.w); put(q.a, q.c, q.b, q.w); put(q.b, q.a, q.c, q.w);
+                put(q.b, q.c, q.a, q.w); put(q.c, q.a, q.b, q.w); put(q.c, q.b, q.a, q.w);
+            }
+        }
+        t.dun_n[r] = n;
+    }
+}
+
+}  // namespace pa
