@@ -1,0 +1,88 @@
+"""Build libproton_amd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+One translation unit per (cell degree, face degree, quadrature kind) listed in
+csrc/pa_configs.def, compiled in parallel, plus csrc/capi.hip; linked into
+proton_amd/lib/libproton_amd.so.  hipcc cross-compiles without a GPU.
+"""
+import concurrent.futures
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
+LIB_PATH = os.path.join(HERE, "lib", "libproton_amd.so")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: cannot build the HIP extension")
+    return exe
+
+
+def configs():
+    out = []
+    with open(os.path.join(CSRC, "pa_configs.def")) as f:
+        for line in f:
+            m = re.match(r"\s*PA_CONFIG\(\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*\)", line)
+            if m:
+                out.append(tuple(int(x) for x in m.groups()))
+    return out
+
+
+def _deps_mtime():
+    names = ["hho_device.hpp", "hho_launch.hpp", "hho_aux.hpp", "quad_tables.hpp", "pa_configs.def",
+             "hho_inst.hip", "capi.hip", os.path.join("..", "..", "include", "proton_amd.h"),
+             os.path.join("..", "_build.py")]
+    return max(os.path.getmtime(os.path.join(CSRC, n)) for n in names)
+
+
+def _compile(job):
+    src, obj, defs = job
+    cmd = [hipcc()] + FLAGS + defs + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+    return obj
+
+
+def build(force=False, verbose=False, jobs=None):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    newest = _deps_mtime()
+    todo, objs = [], []
+    for (cd, fd, q, gmin) in configs():
+        obj = os.path.join(OBJ_DIR, "inst_%d_%d_%d.o" % (cd, fd, q))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+            todo.append((os.path.join(CSRC, "hho_inst.hip"), obj,
+                         ["-DPA_CD=%d" % cd, "-DPA_FD=%d" % fd, "-DPA_QUAD=%d" % q, "-DPA_GMIN=%d" % gmin]))
+    capi_obj = os.path.join(OBJ_DIR, "capi.o")
+    objs.append(capi_obj)
+    if force or not os.path.exists(capi_obj) or os.path.getmtime(capi_obj) < newest:
+        todo.append((os.path.join(CSRC, "capi.hip"), capi_obj, []))
+    if todo:
+        if verbose:
+            print("proton_amd: compiling %d translation units for %s" % (len(todo), ARCH), flush=True)
+        jobs = jobs or min(8, os.cpu_count() or 1)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+            for obj in ex.map(_compile, todo):
+                if verbose:
+                    print("  built", os.path.basename(obj), flush=True)
+    if todo or not os.path.exists(LIB_PATH):
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+        if verbose:
+            print("proton_amd: linked", LIB_PATH, flush=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

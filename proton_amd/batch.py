@@ -1,0 +1,99 @@
+"""Torch-tensor convenience layer over the C ABI (device memory + streams only).
+
+All compute happens inside libproton_amd.so; torch provides allocations and the stream.
+"""
+import numpy as np
+import torch
+
+from . import capi
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class BatchAssembler:
+    """Batched counterpart of the reference's per-cell loop (convergence_test.cpp:202-213):
+    make_hho_laplacian + stabilization (+ make_rhs) for a block of cells, on one GPU."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("proton_amd needs a GPU: torch.cuda.is_available() is False (no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else None
+        self.ctx = capi.Context(device, stream)
+        self._keep = []
+
+    # ---- mesh -----------------------------------------------------------------------
+    def set_mesh(self, points, ptids):
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        ptids = np.ascontiguousarray(ptids)
+        assert ptids.max() < 2 ** 32
+        self.ctx.mesh_upload(points, ptids.astype(np.uint32))
+
+    def generate_mesh(self, Nx, Ny, lo=(0.0, 0.0), hi=(1.0, 1.0), rows=None):
+        self.ctx.mesh_generate(Nx, Ny, lo, hi, rows)
+
+    @property
+    def ncells(self):
+        return self.ctx.mesh_counts()[1]
+
+    # ---- hot path -------------------------------------------------------------------
+    def local_ops(self, cd, fd, quad=capi.QUAD_TENSOR, stab=capi.STAB_FANCY, first=0, n=None,
+                  want=("lc",), out=None):
+        """Returns dict of cell-major torch tensors [n, cols, rows] (column-major matrices:
+        entry (i, j) is t[c, j, i]); `out` may carry preallocated tensors to reuse."""
+        di, _ = capi.degree_info(cd, fd)
+        sz = capi.sizes_for(di, quad)
+        if n is None:
+            n = self.ncells - first
+        out = dict(out or {})
+        shapes = {"oper": (n, sz.msize, sz.oper_rows), "data": (n, sz.msize, sz.msize),
+                  "stab": (n, sz.msize, sz.msize), "lc": (n, sz.msize, sz.msize)}
+        for k in want:
+            if k == "info":
+                if "info" not in out:
+                    out["info"] = torch.empty(n, dtype=torch.int32, device=self.device)
+            elif k not in out:
+                out[k] = torch.empty(shapes[k], dtype=torch.float64, device=self.device)
+        self.ctx.local_ops(di, quad, stab, first, n, _ptr(out.get("oper")), _ptr(out.get("data")),
+                           _ptr(out.get("stab")), _ptr(out.get("lc")), _ptr(out.get("info")))
+        return out
+
+    def cell_rhs(self, degree, fn, quad=capi.QUAD_TENSOR, dinc=0, first=0, n=None, fvals=None, out=None):
+        if n is None:
+            n = self.ncells - first
+        cbs = (degree + 2) * (degree + 1) // 2
+        if out is None:
+            out = torch.empty((n, cbs), dtype=torch.float64, device=self.device)
+        self.ctx.cell_rhs(degree, dinc, quad, fn, first, n, out.data_ptr(), _ptr(fvals))
+        return out
+
+    def quadrature_points(self, degree, quad=capi.QUAD_TENSOR, first=0, n=None):
+        if n is None:
+            n = self.ncells - first
+        nq = self.ctx.cell_quadrature_points(degree, quad, first, n, None)
+        out = torch.empty((n, nq, 3), dtype=torch.float64, device=self.device)
+        self.ctx.cell_quadrature_points(degree, quad, first, n, out.data_ptr())
+        return out
+
+    def static_condensation(self, cd, fd, lc, rhs=None):
+        di, _ = capi.degree_info(cd, fd)
+        sz = capi.sizes_for(di, capi.QUAD_TENSOR)
+        n, nf = lc.shape[0], 4 * sz.fbs
+        S = torch.empty((n, nf, nf), dtype=torch.float64, device=self.device)
+        g = torch.empty((n, nf), dtype=torch.float64, device=self.device)
+        rec = torch.empty((n, nf + 1, sz.cbs), dtype=torch.float64, device=self.device)
+        info = torch.empty(n, dtype=torch.int32, device=self.device)
+        self.ctx.static_condensation(di, n, lc.data_ptr(), _ptr(rhs), S.data_ptr(), g.data_ptr(), rec.data_ptr(),
+                                     info.data_ptr())
+        return S, g, rec, info
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+
+def to_rowcol(t):
+    """[n, cols, rows] device tensor of column-major matrices -> numpy [n, rows, cols]."""
+    return t.detach().cpu().numpy().swapaxes(1, 2).copy()

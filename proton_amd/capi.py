@@ -1,0 +1,176 @@
+"""ctypes binding of libproton_amd.so (the C ABI in include/proton_amd.h).
+
+Plumbing only: the product is the shared library.  There is NO CPU fallback -- if the
+library is missing or the GPU is absent the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libproton_amd.so")
+
+QUAD_TENSOR, QUAD_FAN = 0, 1
+STAB_NONE, STAB_NAIVE, STAB_FANCY = 0, 1, 2
+FN_SAMPLED, FN_SIN_SIN_RHS, FN_SIN_SIN_SOL, FN_OBSTACLE_RHS, FN_OBSTACLE_SOL, FN_ONE = range(6)
+
+STATUS = {0: "PA_OK", 1: "PA_ERR_INVALID_ARG", 2: "PA_ERR_INVALID_DEGREE", 3: "PA_ERR_QUADRATURE",
+          4: "PA_ERR_HIP", 5: "PA_ERR_NO_MESH", 6: "PA_ERR_NOT_SPD"}
+
+# every symbol include/proton_amd.h declares
+EXPORTS = [
+    "pa_abi_version", "pa_degree_info_equal", "pa_degree_info_make", "pa_sizes_for",
+    "pa_context_create", "pa_context_destroy", "pa_context_synchronize", "pa_last_error",
+    "pa_malloc", "pa_free", "pa_memcpy_h2d", "pa_memcpy_d2h", "pa_memset",
+    "pa_mesh_upload", "pa_mesh_attach_device", "pa_mesh_generate", "pa_mesh_counts",
+    "pa_local_ops_batch", "pa_cell_rhs_batch", "pa_cell_quadrature_points",
+    "pa_static_condensation_batch", "pa_local_ops_launch_info",
+]
+
+
+class DegreeInfo(C.Structure):
+    _fields_ = [("cell_deg", C.c_int32), ("face_deg", C.c_int32), ("rec_deg", C.c_int32)]
+
+
+class Sizes(C.Structure):
+    _fields_ = [("rbs", C.c_int32), ("cbs", C.c_int32), ("fbs", C.c_int32), ("msize", C.c_int32),
+                ("oper_rows", C.c_int32), ("cell_qps", C.c_int32), ("face_qps", C.c_int32)]
+
+
+class LaunchInfo(C.Structure):
+    _fields_ = [("lanes_per_cell", C.c_int32), ("cells_per_block", C.c_int32), ("block_threads", C.c_int32),
+                ("lds_bytes_per_block", C.c_int32), ("grid_blocks", C.c_int32), ("kernel_name", C.c_char_p)]
+
+
+class ProtonAmdError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__("%s failed: %s%s" % (where, STATUS.get(status, status), (" (" + detail + ")") if detail else ""))
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (raises if it has not been built: no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("proton_amd: %s is missing -- run `python -m proton_amd._build` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, dp = C.c_void_p, C.c_size_t, C.c_void_p
+    L.pa_abi_version.restype = C.c_int
+    L.pa_degree_info_equal.restype = DegreeInfo
+    L.pa_degree_info_equal.argtypes = [C.c_int]
+    L.pa_degree_info_make.restype = DegreeInfo
+    L.pa_degree_info_make.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.pa_sizes_for.argtypes = [DegreeInfo, C.c_int, C.POINTER(Sizes)]
+    L.pa_context_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.pa_context_destroy.argtypes = [vp]
+    L.pa_context_synchronize.argtypes = [vp]
+    L.pa_last_error.argtypes = [vp]
+    L.pa_last_error.restype = C.c_char_p
+    L.pa_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.pa_free.argtypes = [vp, vp]
+    L.pa_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    L.pa_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    L.pa_memset.argtypes = [vp, vp, C.c_int, sz]
+    L.pa_mesh_upload.argtypes = [vp, vp, sz, vp, sz]
+    L.pa_mesh_attach_device.argtypes = [vp, dp, sz, dp, sz]
+    L.pa_mesh_generate.argtypes = [vp, sz, sz, C.c_double, C.c_double, C.c_double, C.c_double, sz, sz]
+    L.pa_mesh_counts.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+    L.pa_local_ops_batch.argtypes = [vp, DegreeInfo, C.c_int, C.c_int, sz, sz, dp, dp, dp, dp, dp]
+    L.pa_cell_rhs_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp, sz, sz, dp]
+    L.pa_cell_quadrature_points.argtypes = [vp, C.c_int, C.c_int, sz, sz, dp, C.POINTER(C.c_int32)]
+    L.pa_static_condensation_batch.argtypes = [vp, DegreeInfo, sz, dp, dp, dp, dp, dp, dp]
+    L.pa_local_ops_launch_info.argtypes = [vp, DegreeInfo, C.c_int, C.c_int, sz, C.POINTER(LaunchInfo)]
+    _lib = L
+    return L
+
+
+def degree_info(cd, fd):
+    fb = C.c_int(0)
+    d = lib().pa_degree_info_make(cd, fd, C.byref(fb))
+    return d, bool(fb.value)
+
+
+def sizes_for(di, quad):
+    s = Sizes()
+    st = lib().pa_sizes_for(di, quad, C.byref(s))
+    if st != 0:
+        raise ProtonAmdError(st, "pa_sizes_for")
+    return s
+
+
+class Context:
+    """RAII wrapper of pa_context.  `stream` is a raw hipStream_t handle (int) or None."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = lib()
+        h = C.c_void_p()
+        st = self._L.pa_context_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if st != 0:
+            raise ProtonAmdError(st, "pa_context_create", "is a GPU visible?")
+        self.h = h
+        self.device = device
+
+    def _ck(self, st, where):
+        if st != 0:
+            raise ProtonAmdError(st, where, self._L.pa_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self._L.pa_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._ck(self._L.pa_context_synchronize(self.h), "pa_context_synchronize")
+
+    def mesh_upload(self, points, ptids):
+        import numpy as np
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        ptids = np.ascontiguousarray(ptids, dtype=np.uint32)
+        self._ck(self._L.pa_mesh_upload(self.h, points.ctypes.data, points.shape[0], ptids.ctypes.data, ptids.shape[0]),
+                 "pa_mesh_upload")
+
+    def mesh_attach_device(self, d_points, npoints, d_ptids, ncells):
+        self._ck(self._L.pa_mesh_attach_device(self.h, d_points, npoints, d_ptids, ncells), "pa_mesh_attach_device")
+
+    def mesh_generate(self, Nx, Ny, lo=(0.0, 0.0), hi=(1.0, 1.0), rows=None):
+        r0, r1 = rows if rows is not None else (0, Ny)
+        self._ck(self._L.pa_mesh_generate(self.h, Nx, Ny, lo[0], hi[0], lo[1], hi[1], r0, r1), "pa_mesh_generate")
+
+    def mesh_counts(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        self._ck(self._L.pa_mesh_counts(self.h, C.byref(a), C.byref(b)), "pa_mesh_counts")
+        return a.value, b.value
+
+    def local_ops(self, di, quad, stab, first, n, oper=None, data=None, stab_out=None, lc=None, info=None):
+        """Device pointers (ints) or None.  Asynchronous on the context's stream."""
+        self._ck(self._L.pa_local_ops_batch(self.h, di, quad, stab, first, n, oper, data, stab_out, lc, info),
+                 "pa_local_ops_batch")
+
+    def cell_rhs(self, degree, dinc, quad, fn, first, n, rhs, fvals=None):
+        self._ck(self._L.pa_cell_rhs_batch(self.h, degree, dinc, quad, fn, fvals, first, n, rhs), "pa_cell_rhs_batch")
+
+    def cell_quadrature_points(self, degree, quad, first, n, xyw=None):
+        nq = C.c_int32(0)
+        self._ck(self._L.pa_cell_quadrature_points(self.h, degree, quad, first, n, xyw, C.byref(nq)),
+                 "pa_cell_quadrature_points")
+        return nq.value
+
+    def static_condensation(self, di, n, lc, rhs=None, S=None, g=None, rec=None, info=None):
+        self._ck(self._L.pa_static_condensation_batch(self.h, di, n, lc, rhs, S, g, rec, info),
+                 "pa_static_condensation_batch")
+
+    def launch_info(self, di, quad, stab, n):
+        li = LaunchInfo()
+        self._ck(self._L.pa_local_ops_launch_info(self.h, di, quad, stab, n, C.byref(li)), "pa_local_ops_launch_info")
+        return li

@@ -1,0 +1,452 @@
+// capi.hip -- implementation of the C ABI declared in include/proton_amd.h.
+// Thin: argument validation, kernel selection, launches on the context's stream.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/proton_amd.h"
+#include "hho_aux.hpp"
+#include "hho_launch.hpp"
+#include "quad_tables.hpp"
+
+// ---- registry of instantiated kernels (one getter per translation unit, see pa_configs.def) ----
+#define PA_CONFIG(cd, fd, q, gmin) extern "C" const pa::KernelEntry *pa_entries_##cd##_##fd##_##q(int *count);
+#include "pa_configs.def"
+#undef PA_CONFIG
+
+namespace {
+
+typedef const pa::KernelEntry *(*entries_getter)(int *);
+struct ConfigRow { int cd, fd, quad, gmin; entries_getter get; };
+const ConfigRow k_configs[] = {
+#define PA_CONFIG(cd, fd, q, gmin) {cd, fd, q, gmin, &pa_entries_##cd##_##fd##_##q},
+#include "pa_configs.def"
+#undef PA_CONFIG
+};
+
+const pa::KernelEntry *find_kernel(int cd, int fd, int quad, int stab, int lanes)
+{
+    for (const ConfigRow &row : k_configs) {
+        if (row.cd != cd || row.fd != fd || row.quad != quad) continue;
+        int n = 0;
+        const pa::KernelEntry *e = row.get(&n);
+        for (int i = 0; i < n; ++i)
+            if (e[i].stab == stab && e[i].lanes_per_cell == lanes) return &e[i];
+    }
+    return nullptr;
+}
+
+int min_lanes(int cd, int fd, int quad)
+{
+    for (const ConfigRow &row : k_configs)
+        if (row.cd == cd && row.fd == fd && row.quad == quad) return row.gmin;
+    return 0;
+}
+
+}  // namespace
+
+struct pa_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int num_cus = 256;
+    pa::QuadTables host_tab;
+    pa::QuadTables *d_tab = nullptr;
+    // mesh
+    double *d_points = nullptr;
+    uint32_t *d_ptids = nullptr;
+    size_t npoints = 0, ncells = 0;
+    bool owns_mesh = false;
+    std::string last_error;
+};
+
+#define PA_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);                \
+            return PA_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+static void release_mesh(pa_context *ctx)
+{
+    if (ctx->owns_mesh) {
+        if (ctx->d_points) (void)hipFree(ctx->d_points);
+        if (ctx->d_ptids) (void)hipFree(ctx->d_ptids);
+    }
+    ctx->d_points = nullptr; ctx->d_ptids = nullptr; ctx->npoints = ctx->ncells = 0; ctx->owns_mesh = false;
+}
+
+extern "C" {
+
+int pa_abi_version(void) { return PA_ABI_VERSION; }
+
+pa_degree_info pa_degree_info_equal(int degree)
+{
+    pa_degree_info d = {degree, degree, degree + 1};
+    return d;
+}
+
+pa_degree_info pa_degree_info_make(int cd, int fd, int *fell_back)
+{
+    // utils.hpp:75-95
+    const bool c1 = fd > 0 && (cd == fd - 1 || cd == fd || cd == fd + 1);
+    const bool c2 = fd == 0 && (cd == fd || cd == fd + 1);
+    pa_degree_info d;
+    if (c1 || c2) { d.cell_deg = cd; d.face_deg = fd; d.rec_deg = fd + 1; }
+    else { d.cell_deg = fd; d.face_deg = fd; d.rec_deg = fd + 1; }     // "Reverting to equal-order"
+    if (fell_back) *fell_back = !(c1 || c2);
+    return d;
+}
+
+int pa_sizes_for(pa_degree_info di, int quad_kind, pa_sizes *out)
+{
+    if (!out || di.cell_deg < 0 || di.face_deg < 0 || di.rec_deg != di.face_deg + 1) return PA_ERR_INVALID_ARG;
+    if (quad_kind != PA_QUAD_TENSOR && quad_kind != PA_QUAD_FAN) return PA_ERR_INVALID_ARG;
+    out->rbs = pa::P2(di.rec_deg);
+    out->cbs = pa::P2(di.cell_deg);
+    out->fbs = di.face_deg + 1;
+    out->msize = out->cbs + 4 * out->fbs;
+    out->oper_rows = out->rbs - 1;
+    const int qdeg = 2 * di.rec_deg;
+    if (quad_kind == PA_QUAD_TENSOR) {
+        const int n = pa::gauss_nodes(qdeg);
+        if (n > 5) return PA_ERR_QUADRATURE;          // would need golub_welsch (quadratures.hpp:32-75)
+        out->cell_qps = n * n;
+    } else {
+        if (qdeg > 8) return PA_ERR_QUADRATURE;       // quadratures.hpp:245-246
+        out->cell_qps = 4 * pa::dunavant_points(qdeg);
+    }
+    out->face_qps = pa::gauss_nodes(2 * di.face_deg);
+    return PA_OK;
+}
+
+int pa_context_create(int device, void *stream, pa_context **out)
+{
+    if (!out) return PA_ERR_INVALID_ARG;
+    *out = nullptr;
+    pa_context *ctx = new (std::nothrow) pa_context();
+    if (!ctx) return PA_ERR_INVALID_ARG;
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) {
+        if (stream) { ctx->stream = (hipStream_t)stream; ctx->owns_stream = false; }
+        else { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); ctx->owns_stream = true; }
+    }
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+        pa::fill_gauss(ctx->host_tab);
+        pa::fill_dunavant(ctx->host_tab);
+        e = hipMalloc((void **)&ctx->d_tab, sizeof(pa::QuadTables));
+    }
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_tab, &ctx->host_tab, sizeof(pa::QuadTables), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        std::fprintf(stderr, "proton_amd: pa_context_create failed: %s\n", hipGetErrorString(e));
+        if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+        if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return PA_ERR_HIP;
+    }
+    *out = ctx;
+    return PA_OK;
+}
+
+int pa_context_destroy(pa_context *ctx)
+{
+    if (!ctx) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    release_mesh(ctx);
+    if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PA_OK;
+}
+
+int pa_context_synchronize(pa_context *ctx)
+{
+    if (!ctx) return PA_ERR_INVALID_ARG;
+    PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PA_OK;
+}
+
+const char *pa_last_error(pa_context *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int pa_malloc(pa_context *ctx, size_t bytes, void **d_out)
+{
+    if (!ctx || !d_out) return PA_ERR_INVALID_ARG;
+    PA_HIP(ctx, hipSetDevice(ctx->device));
+    PA_HIP(ctx, hipMalloc(d_out, bytes ? bytes : 1));
+    return PA_OK;
+}
+
+int pa_free(pa_context *ctx, void *d_ptr)
+{
+    if (!ctx) return PA_ERR_INVALID_ARG;
+    if (d_ptr) PA_HIP(ctx, hipFree(d_ptr));
+    return PA_OK;
+}
+
+int pa_memcpy_h2d(pa_context *ctx, void *d_dst, const void *src, size_t bytes)
+{
+    if (!ctx || (!d_dst && bytes) || (!src && bytes)) return PA_ERR_INVALID_ARG;
+    PA_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PA_OK;
+}
+
+int pa_memcpy_d2h(pa_context *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (!ctx || (!dst && bytes) || (!d_src && bytes)) return PA_ERR_INVALID_ARG;
+    PA_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PA_OK;
+}
+
+int pa_memset(pa_context *ctx, void *d_dst, int value, size_t bytes)
+{
+    if (!ctx || (!d_dst && bytes)) return PA_ERR_INVALID_ARG;
+    PA_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return PA_OK;
+}
+
+// ---- mesh ---------------------------------------------------------------------------------
+int pa_mesh_upload(pa_context *ctx, const double *points, size_t npoints, const uint32_t *cell_ptids, size_t ncells)
+{
+    if (!ctx || !points || !cell_ptids || npoints == 0) return PA_ERR_INVALID_ARG;
+    for (size_t i = 0; i < 4 * ncells; ++i)
+        if (cell_ptids[i] >= npoints) return PA_ERR_INVALID_ARG;      // the kernels gather points[ptid] unchecked
+    PA_HIP(ctx, hipSetDevice(ctx->device));
+    release_mesh(ctx);
+    ctx->owns_mesh = true;
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_points, npoints * 2 * sizeof(double)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_ptids, (ncells ? ncells : 1) * 4 * sizeof(uint32_t)));
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_points, points, npoints * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_ptids, cell_ptids, ncells * 4 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->npoints = npoints; ctx->ncells = ncells;
+    return PA_OK;
+}
+
+int pa_mesh_attach_device(pa_context *ctx, const double *d_points, size_t npoints, const uint32_t *d_cell_ptids, size_t ncells)
+{
+    if (!ctx || !d_points || !d_cell_ptids || npoints == 0) return PA_ERR_INVALID_ARG;
+    release_mesh(ctx);
+    ctx->d_points = const_cast<double *>(d_points);
+    ctx->d_ptids = const_cast<uint32_t *>(d_cell_ptids);
+    ctx->npoints = npoints; ctx->ncells = ncells; ctx->owns_mesh = false;
+    return PA_OK;
+}
+
+int pa_mesh_generate(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
+                     size_t row_begin, size_t row_end)
+{
+    if (!ctx || Nx == 0 || Ny == 0 || row_begin >= row_end || row_end > Ny) return PA_ERR_INVALID_ARG;
+    const size_t rows = row_end - row_begin;
+    const size_t np = (Nx + 1) * (rows + 1), nc = Nx * rows;
+    if (np >= ((size_t)1 << 32)) return PA_ERR_INVALID_ARG;
+    PA_HIP(ctx, hipSetDevice(ctx->device));
+    release_mesh(ctx);
+    ctx->owns_mesh = true;
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_points, np * 2 * sizeof(double)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_ptids, nc * 4 * sizeof(uint32_t)));
+    const double hx = (max_x - min_x) / (double)Nx, hy = (max_y - min_y) / (double)Ny;    // basic_mesh.hpp:190-196
+    const int block = 256;
+    const int grid = (int)((np + block - 1) / block < 65535 ? (np + block - 1) / block : 65535);
+    hipLaunchKernelGGL(pa::mesh_generate_kernel, dim3(grid), dim3(block), 0, ctx->stream, ctx->d_points, ctx->d_ptids,
+                       Nx, row_begin, row_end, min_x, hx, min_y, hy);
+    PA_HIP(ctx, hipGetLastError());
+    ctx->npoints = np; ctx->ncells = nc;
+    return PA_OK;
+}
+
+int pa_mesh_counts(pa_context *ctx, size_t *npoints, size_t *ncells)
+{
+    if (!ctx) return PA_ERR_INVALID_ARG;
+    if (npoints) *npoints = ctx->npoints;
+    if (ncells) *ncells = ctx->ncells;
+    return PA_OK;
+}
+
+// ---- the hot path -------------------------------------------------------------------------
+static int pick_lanes(int cd, int fd, int quad)
+{
+    const int gmin = min_lanes(cd, fd, quad);
+    if (gmin == 0) return 0;
+    int lanes = gmin;                                   // fewest lanes per cell = most cells per wavefront
+    if (const char *env = std::getenv("PA_LANES_PER_CELL")) {
+        const int v = std::atoi(env);
+        if ((v == 16 || v == 32 || v == 64) && v >= gmin) lanes = v;
+    }
+    return lanes;
+}
+
+static int select_kernel(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t n,
+                         const pa::KernelEntry **entry, int *grid)
+{
+    pa_sizes sz;
+    const int st = pa_sizes_for(di, quad_kind, &sz);
+    if (st != PA_OK) return st;
+    if (stab_kind < PA_STAB_NONE || stab_kind > PA_STAB_FANCY) return PA_ERR_INVALID_ARG;
+    const int lanes = pick_lanes(di.cell_deg, di.face_deg, quad_kind);
+    const pa::KernelEntry *e = lanes ? find_kernel(di.cell_deg, di.face_deg, quad_kind, stab_kind, lanes) : nullptr;
+    if (!e) return PA_ERR_INVALID_DEGREE;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, e->func, 64, e->lds_bytes) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    if (const char *env = std::getenv("PA_BLOCKS_PER_CU")) {
+        const int v = std::atoi(env);
+        if (v > 0) per_cu = v;
+    }
+    const size_t cpb = 64 / lanes;
+    size_t blocks = (n + cpb - 1) / cpb;
+    const size_t resident = (size_t)per_cu * (size_t)ctx->num_cus;
+    if (blocks > resident) blocks = resident;            // persistent: every block loops over its share of cells
+    if (blocks == 0) blocks = 1;
+    *entry = e;
+    *grid = (int)blocks;
+    return PA_OK;
+}
+
+int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t first, size_t n,
+                       double *d_oper, double *d_data, double *d_stab, double *d_lc, int32_t *d_info)
+{
+    if (!ctx) return PA_ERR_INVALID_ARG;
+    if (!ctx->d_points) return PA_ERR_NO_MESH;
+    if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
+    const pa::KernelEntry *e = nullptr;
+    int grid = 0;
+    const int st = select_kernel(ctx, di, quad_kind, stab_kind, n, &e, &grid);
+    if (st != PA_OK) return st;
+    if (n == 0) return PA_OK;
+    pa::LocalOpsArgs a;
+    a.tab = ctx->d_tab; a.points = ctx->d_points; a.ptids = ctx->d_ptids;
+    a.first = first; a.n = n;
+    a.oper = d_oper; a.data = d_data; a.stab = d_stab; a.lc = d_lc; a.info = d_info;
+    PA_HIP(ctx, e->launch(a, grid, ctx->stream));
+    return PA_OK;
+}
+
+int pa_local_ops_launch_info(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t n, pa_launch_info *out)
+{
+    if (!ctx || !out) return PA_ERR_INVALID_ARG;
+    const pa::KernelEntry *e = nullptr;
+    int grid = 0;
+    const int st = select_kernel(ctx, di, quad_kind, stab_kind, n, &e, &grid);
+    if (st != PA_OK) return st;
+    out->lanes_per_cell = e->lanes_per_cell;
+    out->cells_per_block = 64 / e->lanes_per_cell;
+    out->block_threads = 64;
+    out->lds_bytes_per_block = e->lds_bytes;
+    out->grid_blocks = grid;
+    out->kernel_name = e->name;
+    return PA_OK;
+}
+
+}  // extern "C"
+
+// ---- right-hand sides, quadrature points ---------------------------------------------------
+template <int QUAD>
+static int launch_rhs(pa_context *ctx, int degree, int qdeg, int nqp, int fn, const double *d_fvals, size_t first,
+                      size_t n, double *d_rhs)
+{
+    const int block = 256;
+    const int grid = (int)((n + block - 1) / block);
+#define PA_RHS_CASE(D)                                                                                     \
+    case D:                                                                                                \
+        hipLaunchKernelGGL((pa::cell_rhs_kernel<D, QUAD>), dim3(grid), dim3(block), 0, ctx->stream, ctx->d_tab, \
+                           ctx->d_points, ctx->d_ptids, first, n, qdeg, nqp, fn, d_fvals, d_rhs);          \
+        break;
+    switch (degree) {
+        PA_RHS_CASE(0) PA_RHS_CASE(1) PA_RHS_CASE(2) PA_RHS_CASE(3) PA_RHS_CASE(4)
+    default: return PA_ERR_INVALID_DEGREE;
+    }
+#undef PA_RHS_CASE
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
+extern "C" {
+
+static int rhs_quadrature(pa_context *ctx, int qdeg, int quad_kind, int *nqp)
+{
+    if (quad_kind == PA_QUAD_TENSOR) {
+        if (pa::gauss_nodes(qdeg) > 5) return PA_ERR_QUADRATURE;
+    } else if (quad_kind == PA_QUAD_FAN) {
+        if (qdeg > 8) return PA_ERR_QUADRATURE;
+    } else return PA_ERR_INVALID_ARG;
+    *nqp = pa::cell_qp_count(&ctx->host_tab, quad_kind, qdeg);
+    return PA_OK;
+}
+
+int pa_cell_rhs_batch(pa_context *ctx, int degree, int dinc, int quad_kind, int fn, const double *d_fvals,
+                      size_t first, size_t n, double *d_rhs)
+{
+    if (!ctx || !d_rhs || degree < 0 || dinc < 0) return PA_ERR_INVALID_ARG;
+    if (!ctx->d_points) return PA_ERR_NO_MESH;
+    if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
+    if (fn < PA_FN_SAMPLED || fn > PA_FN_ONE || (fn == PA_FN_SAMPLED && !d_fvals)) return PA_ERR_INVALID_ARG;
+    const int qdeg = 2 * (degree + dinc);                          // utils.hpp:165
+    int nqp = 0;
+    const int st = rhs_quadrature(ctx, qdeg, quad_kind, &nqp);
+    if (st != PA_OK) return st;
+    if (n == 0) return PA_OK;
+    return quad_kind == PA_QUAD_TENSOR ? launch_rhs<pa::QUAD_TENSOR>(ctx, degree, qdeg, nqp, fn, d_fvals, first, n, d_rhs)
+                                       : launch_rhs<pa::QUAD_FAN>(ctx, degree, qdeg, nqp, fn, d_fvals, first, n, d_rhs);
+}
+
+int pa_cell_quadrature_points(pa_context *ctx, int degree, int quad_kind, size_t first, size_t n, double *d_xyw,
+                              int32_t *nqp_out)
+{
+    if (!ctx || degree < 0) return PA_ERR_INVALID_ARG;
+    int nqp = 0;
+    const int st = rhs_quadrature(ctx, degree, quad_kind, &nqp);
+    if (st != PA_OK) return st;
+    if (nqp_out) *nqp_out = nqp;
+    if (!d_xyw) return PA_OK;                                       // size query
+    if (!ctx->d_points) return PA_ERR_NO_MESH;
+    if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
+    if (n == 0 || nqp == 0) return PA_OK;
+    const int block = 256;
+    const int grid = (int)((n + block - 1) / block);
+    if (quad_kind == PA_QUAD_TENSOR)
+        hipLaunchKernelGGL((pa::cell_qpoints_kernel<pa::QUAD_TENSOR>), dim3(grid), dim3(block), 0, ctx->stream, ctx->d_tab,
+                           ctx->d_points, ctx->d_ptids, first, n, degree, nqp, d_xyw);
+    else
+        hipLaunchKernelGGL((pa::cell_qpoints_kernel<pa::QUAD_FAN>), dim3(grid), dim3(block), 0, ctx->stream, ctx->d_tab,
+                           ctx->d_points, ctx->d_ptids, first, n, degree, nqp, d_xyw);
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
+// ---- static condensation -------------------------------------------------------------------
+int pa_static_condensation_batch(pa_context *ctx, pa_degree_info di, size_t n, const double *d_lc, const double *d_rhs,
+                                 double *d_S, double *d_g, double *d_rec, int32_t *d_info)
+{
+    if (!ctx || !d_lc) return PA_ERR_INVALID_ARG;
+    pa_sizes sz;
+    const int st = pa_sizes_for(di, PA_QUAD_TENSOR, &sz);
+    if (st != PA_OK && st != PA_ERR_QUADRATURE) return st;
+    if (n == 0) return PA_OK;
+    const size_t resident = (size_t)ctx->num_cus * 16;
+    const int grid = (int)(n < resident ? n : resident);
+#define PA_SC_CASE(CD, FD)                                                                                    \
+    if (di.cell_deg == CD && di.face_deg == FD) {                                                             \
+        hipLaunchKernelGGL((pa::static_condensation_kernel<pa::P2(CD), 4 * (FD + 1)>), dim3(grid), dim3(64), 0, \
+                           ctx->stream, n, d_lc, d_rhs, d_S, d_g, d_rec, d_info);                             \
+        PA_HIP(ctx, hipGetLastError());                                                                       \
+        return PA_OK;                                                                                         \
+    }
+    PA_SC_CASE(1, 0) PA_SC_CASE(0, 0) PA_SC_CASE(2, 1) PA_SC_CASE(1, 1) PA_SC_CASE(0, 1) PA_SC_CASE(3, 2)
+    PA_SC_CASE(2, 2) PA_SC_CASE(1, 2) PA_SC_CASE(4, 3) PA_SC_CASE(3, 3) PA_SC_CASE(2, 3)
+#undef PA_SC_CASE
+    return PA_ERR_INVALID_DEGREE;
+}
+
+}  // extern "C"

@@ -1,0 +1,238 @@
+// hho_aux.hpp -- the smaller kernels around the local-operator kernel:
+//   structured mesh generation   (src/core/core_bits/basic_mesh.hpp:230-298)
+//   cell quadrature points       (src/core/core_bits/quadratures.hpp:311-402)
+//   cell right-hand sides        (src/core/core_bits/utils.hpp:153-174)
+//   static condensation          (not in the reference)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hho_device.hpp"
+
+namespace pa {
+
+enum { FN_SAMPLED = 0, FN_SIN_SIN_RHS = 1, FN_SIN_SIN_SOL = 2, FN_OBSTACLE_RHS = 3, FN_OBSTACLE_SOL = 4, FN_ONE = 5 };
+
+// mesh_impl<T,4>(mesh_init_params): points (min + i*hx, min + j*hy), point id j*(Nx+1)+i;
+// cells {p, p+1, p+Nx+2, p+Nx+1}, cell id j*Nx+i (basic_mesh.hpp:239-264; the sort at :289 is the
+// identity).  The context holds rows [row0, row1): point ids are local to the slab, which keeps
+// their relative order (all the face-basis orientation depends on).
+__global__ void mesh_generate_kernel(double *points, uint32_t *ptids, size_t Nx, size_t row0, size_t row1,
+                                     double min_x, double hx, double min_y, double hy)
+{
+    const size_t npr = Nx + 1;
+    const size_t np = npr * (row1 - row0 + 1), nc = Nx * (row1 - row0);
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < np; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t j = t / npr, i = t % npr;
+        points[2 * t] = min_x + (double)i * hx;                    // parms.min_x + i*hx  :243
+        points[2 * t + 1] = min_y + (double)(row0 + j) * hy;
+        if (t < nc) {
+            const size_t cj = t / Nx, ci = t % Nx;
+            const uint32_t p0 = (uint32_t)(cj * npr + ci);
+            ptids[4 * t + 0] = p0;
+            ptids[4 * t + 1] = p0 + 1;
+            ptids[4 * t + 2] = p0 + (uint32_t)Nx + 2;
+            ptids[4 * t + 3] = p0 + (uint32_t)Nx + 1;
+        }
+    }
+}
+
+struct CellGeom {
+    double px[4], py[4], barx, bary, hT;
+};
+
+__device__ __forceinline__ void load_cell_geom(const double *points, const uint32_t *ptids, size_t cell, CellGeom &c)
+{
+    const uint4 idv = *reinterpret_cast<const uint4 *>(ptids + 4 * cell);
+    const uint32_t ids[4] = {idv.x, idv.y, idv.z, idv.w};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const double2 pt = *reinterpret_cast<const double2 *>(points + 2 * (size_t)ids[v]);
+        c.px[v] = pt.x; c.py[v] = pt.y;
+    }
+    double rx = 0.0, ry = 0.0, den = 0.0;                           // basic_geom.hpp:247-270
+#pragma unroll
+    for (int i = 2; i < 4; ++i) {
+        const double ax = c.px[i - 1] - c.px[0], ay = c.py[i - 1] - c.py[0];
+        const double bx = c.px[i] - c.px[0], by = c.py[i] - c.py[0];
+        const double d = (ax * by - ay * bx) / 2.0;
+        rx += (ax + bx) * d; ry += (ay + by) * d; den += d;
+    }
+    c.barx = c.px[0] + rx / (den * 3); c.bary = c.py[0] + ry / (den * 3);
+    double h = 0.0;                                                 // basic_geom.hpp:288-305
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) {
+            const double dx = c.px[j] - c.px[i], dy = c.py[j] - c.py[i];
+            h = fmax(h, sqrt(dx * dx + dy * dy));
+        }
+    c.hT = h;
+}
+
+// q-th point of integrate(msh, cl, degree): tensor Gauss (quadratures.hpp:311-375) or fan (:377-402)
+template <int QUAD>
+__device__ __forceinline__ void cell_qp(const QuadTables *tab, const CellGeom &c, int degree, int q,
+                                        double &x, double &y, double &w)
+{
+    if (QUAD == QUAD_TENSOR) {
+        const int n = gauss_nodes(degree);
+        const int i = q % n, j = q / n;
+        const double xi = tab->gauss_x[n][i], eta = tab->gauss_x[n][j];
+        x = 0.25 * c.px[0] * (1 - xi) * (1 - eta) + 0.25 * c.px[1] * (1 + xi) * (1 - eta) +
+            0.25 * c.px[2] * (1 + xi) * (1 + eta) + 0.25 * c.px[3] * (1 - xi) * (1 + eta);
+        y = 0.25 * c.py[0] * (1 - xi) * (1 - eta) + 0.25 * c.py[1] * (1 + xi) * (1 - eta) +
+            0.25 * c.py[2] * (1 + xi) * (1 + eta) + 0.25 * c.py[3] * (1 - xi) * (1 + eta);
+        const double j11 = 0.25 * ((c.px[1] - c.px[0]) * (1 - eta) + (c.px[2] - c.px[3]) * (1 + eta));
+        const double j12 = 0.25 * ((c.py[1] - c.py[0]) * (1 - eta) + (c.py[2] - c.py[3]) * (1 + eta));
+        const double j21 = 0.25 * ((c.px[3] - c.px[0]) * (1 - xi) + (c.px[2] - c.px[1]) * (1 + xi));
+        const double j22 = 0.25 * ((c.py[3] - c.py[0]) * (1 - xi) + (c.py[2] - c.py[1]) * (1 + xi));
+        w = tab->gauss_w[n][i] * tab->gauss_w[n][j] * fabs(j11 * j22 - j12 * j21);
+    } else {
+        const int R = degree == 0 ? 1 : degree;                     // rules[deg]  quadratures.hpp:242-257
+        const int nt = tab->dun_n[R];
+        const int t = q / nt, row = q % nt, t1 = (t + 1) & 3;
+        const double ax = c.px[t], ay = c.py[t], bx = c.px[t1], by = c.py[t1];
+        const double v0x = bx - ax, v0y = by - ay, v1x = c.barx - ax, v1y = c.bary - ay;
+        const double tarea = fabs((v0x * v1y - v0y * v1x) / 2.0);
+        const double l0 = tab->dun[R][row][0], l1 = tab->dun[R][row][1], l2 = tab->dun[R][row][2];
+        x = ax * l0 + bx * l1 + c.barx * l2;
+        y = ay * l0 + by * l1 + c.bary * l2;
+        w = tarea * tab->dun[R][row][3];
+    }
+}
+
+__host__ __device__ inline int cell_qp_count(const QuadTables *tab, int quad, int degree)
+{
+    if (quad == QUAD_TENSOR) { const int n = gauss_nodes(degree); return n * n; }
+    return 4 * tab->dun_n[degree == 0 ? 1 : degree];
+}
+
+__device__ __forceinline__ double builtin_fn(int fn, double x, double y)
+{
+    const double pi = 3.14159265358979323846;                       // M_PI
+    switch (fn) {
+    case FN_SIN_SIN_RHS: return 2.0 * pi * pi * sin(pi * x) * sin(pi * y);   // convergence_test.cpp:100-102
+    case FN_SIN_SIN_SOL: return sin(pi * x) * sin(pi * y);                   // convergence_test.cpp:104-106
+    case FN_OBSTACLE_RHS: {                                                  // obstacle.cpp:65-74
+        const double r0 = 0.7, r = sqrt(x * x + y * y);
+        return r > r0 ? -16 * r * r + 8 * r0 * r0 : -8.0 * (r0 * r0 * (r0 * r0 + 1)) + 8 * r0 * r0 * r * r;
+    }
+    case FN_OBSTACLE_SOL: {                                                  // obstacle.cpp:76-81
+        const double r0 = 0.7, r = sqrt(x * x + y * y);
+        const double s = r * r - r0 * r0, t = fmax(s, 0.0);
+        return t * t;
+    }
+    default: return 1.0;
+    }
+}
+
+template <int QUAD>
+__global__ __launch_bounds__(256) void cell_qpoints_kernel(const QuadTables *tab, const double *points,
+                                                           const uint32_t *ptids, size_t first, size_t n,
+                                                           int degree, int nqp, double *xyw)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    CellGeom c;
+    load_cell_geom(points, ptids, first + t, c);
+    for (int q = 0; q < nqp; ++q) {
+        double x, y, w;
+        cell_qp<QUAD>(tab, c, degree, q, x, y, w);
+        double *dst = xyw + (t * nqp + q) * 3;
+        dst[0] = x; dst[1] = y; dst[2] = w;
+    }
+}
+
+// make_rhs(msh, cl, degree, f, di): ret += qp.second * phi * f(qp.first)   utils.hpp:163-171.
+// One thread per cell; DEG is compile time so the accumulators stay in registers.
+template <int DEG, int QUAD>
+__global__ __launch_bounds__(256) void cell_rhs_kernel(const QuadTables *tab, const double *points,
+                                                       const uint32_t *ptids, size_t first, size_t n,
+                                                       int qdegree, int nqp, int fn, const double *fvals,
+                                                       double *rhs)
+{
+    constexpr int CBS = P2(DEG);
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    CellGeom c;
+    load_cell_geom(points, ptids, first + t, c);
+    const double ihalf = 1.0 / (0.5 * c.hT);
+    double acc[CBS];
+#pragma unroll
+    for (int m = 0; m < CBS; ++m) acc[m] = 0.0;
+    for (int q = 0; q < nqp; ++q) {
+        double x, y, w;
+        cell_qp<QUAD>(tab, c, qdegree, q, x, y, w);
+        const double fv = (fn == FN_SAMPLED) ? fvals[t * nqp + q] : builtin_fn(fn, x, y);
+        const double bx = (x - c.barx) * ihalf, by = (y - c.bary) * ihalf;
+        double pwx[DEG + 1], pwy[DEG + 1];
+        pwx[0] = 1.0; pwy[0] = 1.0;
+#pragma unroll
+        for (int e = 1; e <= DEG; ++e) { pwx[e] = pwx[e - 1] * bx; pwy[e] = pwy[e - 1] * by; }
+        int m = 0;
+#pragma unroll
+        for (int kk = 0; kk <= DEG; ++kk)
+#pragma unroll
+            for (int ii = 0; ii <= kk; ++ii, ++m) acc[m] += (w * (pwx[kk - ii] * pwy[ii])) * fv;
+    }
+#pragma unroll
+    for (int m = 0; m < CBS; ++m) rhs[t * CBS + m] = acc[m];
+}
+
+// Static condensation, one wavefront per cell (not on the reference's path; used by the
+// face-DOF triplet path of the multi-GPU exchange).  A = lc (MS x MS), T = first CBS dofs.
+//   rec = A_TT^-1 [ f_T | -A_TF ],  S = A_FF + A_FT rec[:,1:],  g = -A_FT rec[:,0]
+template <int CBS, int NF>
+__global__ __launch_bounds__(64) void static_condensation_kernel(size_t n, const double *lc, const double *rhs,
+                                                                 double *Sout, double *gout, double *recout,
+                                                                 int32_t *info)
+{
+    constexpr int MS = CBS + NF, G = 64;
+    static_assert(NF + 1 <= G && CBS <= G, "one lane per column");
+    __shared__ double A[MS * MS];
+    __shared__ double LT[CBS * CBS];
+    __shared__ double REC[CBS * (NF + 1)];
+    const int l = threadIdx.x;
+    for (size_t cell = blockIdx.x; cell < n; cell += gridDim.x) {
+        const double *src = lc + cell * (size_t)(MS * MS);
+        for (int e = l; e < MS * MS; e += G) A[e] = src[e];
+        __syncthreads();
+        for (int e = l; e < CBS * CBS; e += G) LT[e] = A[(e % CBS) + (e / CBS) * MS];
+        __syncthreads();
+        const int bad = lds_cholesky<CBS, CBS, G>(LT, l);
+        {
+            double x[CBS];
+            const int c = l <= NF ? l : 0;
+#pragma unroll
+            for (int i = 0; i < CBS; ++i)
+                x[i] = (c == 0) ? (rhs != nullptr ? rhs[cell * CBS + i] : 0.0) : -A[i + (CBS + c - 1) * MS];
+            lds_forward<CBS, CBS>(LT, x);
+            lds_backward<CBS, CBS>(LT, x);
+            if (l <= NF) {
+#pragma unroll
+                for (int i = 0; i < CBS; ++i) REC[i + c * CBS] = x[i];
+            }
+        }
+        __syncthreads();
+        if (Sout != nullptr)
+            for (int e = l; e < NF * NF; e += G) {
+                const int i = e % NF, j = e / NF;
+                double s = A[(CBS + i) + (CBS + j) * MS];
+                for (int k = 0; k < CBS; ++k) s += A[(CBS + i) + k * MS] * REC[k + (1 + j) * CBS];
+                Sout[cell * (size_t)(NF * NF) + e] = s;
+            }
+        if (gout != nullptr && l < NF) {
+            double s = 0.0;
+            for (int k = 0; k < CBS; ++k) s -= A[(CBS + l) + k * MS] * REC[k];
+            gout[cell * NF + l] = s;
+        }
+        if (recout != nullptr)
+            for (int e = l; e < CBS * (NF + 1); e += G) recout[cell * (size_t)(CBS * (NF + 1)) + e] = REC[e];
+        if (info != nullptr && l == 0) info[cell] = bad;
+        __syncthreads();
+    }
+}
+
+}  // namespace pa

@@ -184,12 +184,22 @@ __device__ __forceinline__ void lds_backward(const double *L, double (&x)[N])
     }
 }
 
-template <int N>
-__device__ __forceinline__ double sel(const double (&v)[N], int i)
+// lane-dependent choice among four register values (kept as scalars: an array indexed this way
+// is demoted to scratch memory)
+__device__ __forceinline__ double sel4(double v0, double v1, double v2, double v3, int i)
 {
-    double r = v[0];
-#pragma unroll
-    for (int k = 1; k < N; ++k) r = (i == k) ? v[k] : r;
+    double r = v0;
+    r = (i == 1) ? v1 : r;
+    r = (i == 2) ? v2 : r;
+    r = (i == 3) ? v3 : r;
+    return r;
+}
+__device__ __forceinline__ uint32_t sel4u(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, int i)
+{
+    uint32_t r = v0;
+    r = (i == 1) ? v1 : r;
+    r = (i == 2) ? v2 : r;
+    r = (i == 3) ? v3 : r;
     return r;
 }
 
@@ -207,7 +217,8 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
 
     extern __shared__ double smem[];
     const int lane = threadIdx.x;
-    const int g = lane / G, l = lane % G;
+    const int g = lane / G, l0 = lane % G;
+    const int l = l0;
     double *S = smem + g * C::LDS_PER_CELL;
     double *FB = smem + C::oFB, *LF = smem + C::oLF, *MF = smem + C::oMF;
     const QuadTables *__restrict__ tab = a.tab;
@@ -289,53 +300,49 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
 
     const size_t stride = (size_t)gridDim.x * C::CPW;
     for (size_t base = (size_t)blockIdx.x * C::CPW; base < a.n; base += stride) {
+        // Re-derive the lane index opaquely per cell: otherwise LICM hoists every per-entry index
+        // computation of every stage out of the cell loop and the kernel spills.
+        int l = l0;
+        asm volatile("" : "+v"(l));
         const bool valid = base + g < a.n;
         const size_t cell = a.first + (valid ? base + g : a.n - 1);
 
         // ================= S0: geometry (every lane of the group, registers) ==========
         const uint4 idv = *reinterpret_cast<const uint4 *>(a.ptids + 4 * cell);
-        const uint32_t ids[4] = {idv.x, idv.y, idv.z, idv.w};
-        double px[4], py[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const double2 pt = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)ids[v]);
-            px[v] = pt.x; py[v] = pt.y;
-        }
+        const double2 q0 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.x);
+        const double2 q1 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.y);
+        const double2 q2 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.z);
+        const double2 q3 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.w);
+        const double px0 = q0.x, py0 = q0.y, px1 = q1.x, py1 = q1.y, px2 = q2.x, py2 = q2.y, px3 = q3.x, py3 = q3.y;
         double barx, bary;                          // barycenter  basic_geom.hpp:247-270
         {
-            double rx = 0.0, ry = 0.0, den = 0.0;
-#pragma unroll
-            for (int i = 2; i < 4; ++i) {
-                const double ax = px[i - 1] - px[0], ay = py[i - 1] - py[0];
-                const double bx = px[i] - px[0], by = py[i] - py[0];
-                const double d = (ax * by - ay * bx) / 2.0;
-                rx += (ax + bx) * d; ry += (ay + by) * d; den += d;
-            }
-            barx = px[0] + rx / (den * 3); bary = py[0] + ry / (den * 3);
+            const double ax = px1 - px0, ay = py1 - py0, bx = px2 - px0, by = py2 - py0;
+            const double cx = px3 - px0, cy = py3 - py0;
+            const double d1 = (ax * by - ay * bx) / 2.0, d2 = (bx * cy - by * cx) / 2.0;
+            const double rx = (ax + bx) * d1 + (bx + cx) * d2, ry = (ay + by) * d1 + (by + cy) * d2;
+            const double den = d1 + d2;
+            barx = px0 + rx / (den * 3); bary = py0 + ry / (den * 3);
         }
-        double hT = 0.0;                            // diameter  basic_geom.hpp:288-305
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = i + 1; j < 4; ++j) {
-                const double dx = px[j] - px[i], dy = py[j] - py[i];
-                hT = fmax(hT, sqrt(dx * dx + dy * dy));
-            }
+        // edge vectors in cell (CCW) order and their lengths: faces, normals, diameter
+        const double e0x = px1 - px0, e0y = py1 - py0, e1x = px2 - px1, e1y = py2 - py1;
+        const double e2x = px3 - px2, e2y = py3 - py2, e3x = px0 - px3, e3y = py0 - py3;
+        const double len0 = sqrt(e0x * e0x + e0y * e0y), len1 = sqrt(e1x * e1x + e1y * e1y);
+        const double len2 = sqrt(e2x * e2x + e2y * e2y), len3 = sqrt(e3x * e3x + e3y * e3y);
+        double hT;                                  // diameter  basic_geom.hpp:288-305
+        {
+            const double d02x = px2 - px0, d02y = py2 - py0, d13x = px3 - px1, d13y = py3 - py1;
+            hT = fmax(fmax(len0, len1), fmax(len2, len3));
+            hT = fmax(hT, fmax(sqrt(d02x * d02x + d02y * d02y), sqrt(d13x * d13x + d13y * d13y)));
+        }
         const double ihalf = 1.0 / (0.5 * hT);      // bx = (x - bar)/(h/2)  bases.hpp:98-99
         const double ih = 2.0 / hT;                 // bases.hpp:142
-        double area = 0.0;                          // measure  basic_geom.hpp:317-334
-#pragma unroll
-        for (int i = 1; i < 3; ++i) {
-            const double ux = px[i] - px[0], uy = py[i] - py[0];
-            const double vx = px[i + 1] - px[0], vy = py[i + 1] - py[0];
-            area += fabs(ux * vy - uy * vx) * 0.5;
+        double area;                                // measure  basic_geom.hpp:317-334
+        {
+            const double ux = px1 - px0, uy = py1 - py0, vx = px2 - px0, vy = py2 - py0;
+            const double wx = px3 - px0, wy = py3 - py0;
+            area = fabs(ux * vy - uy * vx) * 0.5 + fabs(vx * wy - vy * wx) * 0.5;
         }
-        double hsf[4];                              // |F|/2 per local face: M_F = hsf * M^
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const double ex = px[(f + 1) & 3] - px[f], ey = py[(f + 1) & 3] - py[f];
-            hsf[f] = 0.5 * sqrt(ex * ex + ey * ey);
-        }
+        const double hs0 = 0.5 * len0, hs1 = 0.5 * len1, hs2 = 0.5 * len2, hs3 = 0.5 * len3;   // |F|/2: M_F = hs * M^
 
         // ================= S1: evaluation points ======================================
 #pragma unroll
@@ -347,19 +354,19 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                 if (is_cell) {
                     if (C::QUAD == QUAD_TENSOR) {
                         const double xi = r0[r], eta = r1[r];      // quadratures.hpp:331-352
-                        x = 0.25 * px[0] * (1 - xi) * (1 - eta) + 0.25 * px[1] * (1 + xi) * (1 - eta) +
-                            0.25 * px[2] * (1 + xi) * (1 + eta) + 0.25 * px[3] * (1 - xi) * (1 + eta);
-                        y = 0.25 * py[0] * (1 - xi) * (1 - eta) + 0.25 * py[1] * (1 + xi) * (1 - eta) +
-                            0.25 * py[2] * (1 + xi) * (1 + eta) + 0.25 * py[3] * (1 - xi) * (1 + eta);
-                        const double j11 = 0.25 * ((px[1] - px[0]) * (1 - eta) + (px[2] - px[3]) * (1 + eta));
-                        const double j12 = 0.25 * ((py[1] - py[0]) * (1 - eta) + (py[2] - py[3]) * (1 + eta));
-                        const double j21 = 0.25 * ((px[3] - px[0]) * (1 - xi) + (px[2] - px[1]) * (1 + xi));
-                        const double j22 = 0.25 * ((py[3] - py[0]) * (1 - xi) + (py[2] - py[1]) * (1 + xi));
+                        x = 0.25 * px0 * (1 - xi) * (1 - eta) + 0.25 * px1 * (1 + xi) * (1 - eta) +
+                            0.25 * px2 * (1 + xi) * (1 + eta) + 0.25 * px3 * (1 - xi) * (1 + eta);
+                        y = 0.25 * py0 * (1 - xi) * (1 - eta) + 0.25 * py1 * (1 + xi) * (1 - eta) +
+                            0.25 * py2 * (1 + xi) * (1 + eta) + 0.25 * py3 * (1 - xi) * (1 + eta);
+                        const double j11 = 0.25 * ((px1 - px0) * (1 - eta) + (px2 - px3) * (1 + eta));
+                        const double j12 = 0.25 * ((py1 - py0) * (1 - eta) + (py2 - py3) * (1 + eta));
+                        const double j21 = 0.25 * ((px3 - px0) * (1 - xi) + (px2 - px1) * (1 + xi));
+                        const double j22 = 0.25 * ((py3 - py0) * (1 - xi) + (py2 - py1) * (1 + xi));
                         w = rw[r] * fabs(j11 * j22 - j12 * j21);
                     } else {
                         const int t = p / C::NT;                   // fan triangle (p_t, p_{t+1}, bar)  quadratures.hpp:390-396
-                        const double ax = sel(px, t), ay = sel(py, t);
-                        const double bx = sel(px, (t + 1) & 3), by = sel(py, (t + 1) & 3);
+                        const double ax = sel4(px0, px1, px2, px3, t), ay = sel4(py0, py1, py2, py3, t);
+                        const double bx = sel4(px1, px2, px3, px0, t), by = sel4(py1, py2, py3, py0, t);
                         const double v0x = bx - ax, v0y = by - ay, v1x = barx - ax, v1y = bary - ay;
                         const double tarea = fabs((v0x * v1y - v0y * v1x) / 2.0);      // quadratures.hpp:248-251
                         x = ax * r0[r] + bx * r1[r] + barx * r2[r];
@@ -367,17 +374,12 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                         w = tarea * rw[r];
                     }
                 } else {
-                    const int f = (p - NQ) / NFQ, f1 = (f + 1) & 3;
-                    const double ax = sel(px, f), ay = sel(py, f), bx = sel(px, f1), by = sel(py, f1);
-                    uint32_t ia = ids[0], ib = ids[1];
-#pragma unroll
-                    for (int v = 1; v < 4; ++v) {
-                        ia = (f == v) ? ids[v] : ia;
-                        ib = (f1 == v) ? ids[v] : ib;
-                    }
-                    ib = (f1 == 0) ? ids[0] : ib;
-                    const double ex = bx - ax, ey = by - ay;      // edge in cell (CCW) order
-                    const double len = sqrt(ex * ex + ey * ey);
+                    const int f = (p - NQ) / NFQ;
+                    const double ax = sel4(px0, px1, px2, px3, f), ay = sel4(py0, py1, py2, py3, f);
+                    const double bx = sel4(px1, px2, px3, px0, f), by = sel4(py1, py2, py3, py0, f);
+                    const uint32_t ia = sel4u(idv.x, idv.y, idv.z, idv.w, f), ib = sel4u(idv.y, idv.z, idv.w, idv.x, f);
+                    const double ex = sel4(e0x, e1x, e2x, e3x, f), ey = sel4(e0y, e1y, e2y, e3y, f);   // edge in cell order
+                    const double len = sel4(len0, len1, len2, len3, f);
                     nx = ey / len; ny = -ex / len;                // outward normal  basic_geom.hpp:361-369
                     // the face runs from its LOWER-id endpoint (basic_geom.hpp:202-203, bases.hpp:260-261):
                     // its q-th point sits at -t_q in cell order when the ids are descending
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                 const int e = e0 + l;
                 if (e < NE) {
                     const int m = e / NF, fk = e % NF, f = fk / FBS, k = fk % FBS;
-                    const double hs = sel(hsf, f);
+                    const double hs = sel4(hs0, hs1, hs2, hs3, f);
                     double s = 0.0;
 #pragma unroll
                     for (int q = 0; q < NFQ; ++q)
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < NR; ++k) s += S[C::oY + k + i * NR] * S[C::oY + k + j * NR];
+            asm volatile("" : "+v"(s));          // pin: keeps the FMAs next to their LDS reads (no sinking to S8)
             acc_d[t] = s;
             acc_s[t] = 0.0;
         }
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                     for (int k = 0; k < FBS; ++k) xf[k] = S[C::oFT + (f * FBS + k) + c * NF];
                     lds_forward<FBS, FBS>(LF, xf);
                     lds_backward<FBS, FBS>(LF, xf);
-                    const double ihs = 1.0 / hsf[f];
+                    const double ihs = 1.0 / (f == 0 ? hs0 : f == 1 ? hs1 : f == 2 ? hs2 : hs3);
                     if (l < CBS) {
 #pragma unroll
                         for (int k = 0; k < FBS; ++k) S[C::oPT + (f * FBS + k) + c * NF] = xf[k] * ihs;
@@ -589,9 +592,11 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                     s = -S[C::oFT + (i - CBS) + j * NF];
                 } else {
                     const int fi = (i - CBS) / FBS, fj = (j - CBS) / FBS;
-                    if (fi == fj) s = sel(hsf, fi) * MF[(i - CBS) % FBS + ((j - CBS) % FBS) * FBS];
+                    if (fi == fj) s = sel4(hs0, hs1, hs2, hs3, fi) * MF[(i - CBS) % FBS + ((j - CBS) % FBS) * FBS];
                 }
-                acc_s[t] = s * hinv;
+                s *= hinv;
+                asm volatile("" : "+v"(s));
+                acc_s[t] = s;
             }
         } else if (C::GENERAL_FANCY) {
             // proj1 = [I 0] - M1^{-1} (M2 R)   hho.hpp:184-190
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                 }
                 lds_forward<FBS, FBS>(LF, xf);
                 lds_backward<FBS, FBS>(LF, xf);
-                const double hs = hsf[f], ihs = 1.0 / hs;
+                const double hs = f == 0 ? hs0 : f == 1 ? hs1 : f == 2 ? hs2 : hs3, ihs = 1.0 / hs;
 #pragma unroll
                 for (int k = 0; k < FBS; ++k) {
                     double b = xf[k] * ihs;
@@ -664,7 +669,9 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                 double s = 0.0;
 #pragma unroll
                 for (int r = 0; r < NF; ++r) s += S[C::oTB + r + i * NF] * S[C::oMB + r + j * NF];
-                acc_s[t] = s * hinv;
+                s *= hinv;
+                asm volatile("" : "+v"(s));
+                acc_s[t] = s;
             }
         }
 

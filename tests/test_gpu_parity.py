@@ -1,0 +1,233 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against (a) the committed 50-digit golden fixtures, (b) the CPU oracle on seeded meshes, and
+(c) size-independent properties at BASELINE.json's full sizes.
+
+Tolerance: 1e-12 normwise per cell, max|A - A*| / max|A*| (north_star).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from cases import CELLS
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "local_ops.npz"))
+
+
+def nerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def nerr_cells(a, b):
+    """worst per-cell normwise error of [n, r, c] batches"""
+    num = np.abs(a - b).reshape(a.shape[0], -1).max(axis=1)
+    den = np.abs(b).reshape(b.shape[0], -1).max(axis=1)
+    return (num / np.maximum(den, 1e-300)).max()
+
+
+def gold_cases():
+    seen = []
+    for key in GOLD.files:
+        c, cd, fd, kind, what = key.split("|")
+        t = (c, int(cd), int(fd), kind)
+        if t not in seen:
+            seen.append(t)
+    return seen
+
+
+@pytest.fixture(scope="module")
+def asm():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    from proton_amd.batch import BatchAssembler
+    return BatchAssembler(0)
+
+
+def single_cell_mesh(pts, ids):
+    npts = max(ids) + 1
+    points = np.zeros((npts, 2))
+    # unused slots get distinct far-away coordinates
+    points[:, 0] = 100.0 + np.arange(npts)
+    for v in range(4):
+        points[ids[v]] = pts[v]
+    return points, np.array([ids], dtype=np.uint32)
+
+
+@pytest.mark.parametrize("cname,cd,fd,kind", gold_cases())
+def test_matches_golden(asm, cname, cd, fd, kind):
+    import proton_amd as pa
+    from proton_amd.batch import to_rowcol
+    pts, ids = CELLS[cname]
+    points, ptids = single_cell_mesh(pts, ids)
+    asm.set_mesh(points, ptids)
+    quad = pa.QUAD_TENSOR if kind == "tensor" else pa.QUAD_FAN
+    g = lambda what: GOLD[f"{cname}|{cd}|{fd}|{kind}|{what}"]  # noqa: E731
+    for stab, key in ((pa.STAB_FANCY, "fancy"), (pa.STAB_NAIVE, "naive")):
+        out = asm.local_ops(cd, fd, quad, stab, want=("oper", "data", "stab", "lc", "info"))
+        asm.synchronize()
+        assert int(out["info"].cpu()[0]) == 0
+        assert nerr(to_rowcol(out["oper"])[0], g("oper")) < TOL
+        assert nerr(to_rowcol(out["data"])[0], g("data")) < TOL
+        assert nerr(to_rowcol(out["stab"])[0], g(key)) < TOL
+        assert nerr(to_rowcol(out["lc"])[0], g("data") + g(key)) < TOL
+    # lc-only call (no oper requested) takes the forward-substitution-only path
+    out = asm.local_ops(cd, fd, quad, pa.STAB_FANCY, want=("lc",))
+    assert nerr(to_rowcol(out["lc"])[0], g("data") + g("fancy")) < TOL
+    out = asm.local_ops(cd, fd, quad, pa.STAB_NONE, want=("lc",))
+    assert nerr(to_rowcol(out["lc"])[0], g("data")) < TOL
+    # right-hand side with the convergence_test source term
+    rhs = asm.cell_rhs(cd, pa.capi.FN_SIN_SIN_RHS, quad)
+    assert nerr(rhs.cpu().numpy()[0], g("rhs")[:, 0]) < TOL
+    # static condensation of lc = data + fancy
+    if kind == "tensor":
+        out = asm.local_ops(cd, fd, quad, pa.STAB_FANCY, want=("lc",))
+        S, gg, rec, info = asm.static_condensation(cd, fd, out["lc"], rhs)
+        assert int(info.cpu()[0]) == 0
+        assert nerr(S.cpu().numpy()[0].T, g("S")) < 10 * TOL
+        assert np.abs(gg.cpu().numpy()[0] - g("g")[:, 0]).max() < 10 * TOL * max(np.abs(g("g")).max(), np.abs(g("rhs")).max())
+
+
+def perturbed_mesh(oracle, N, seed, lo=(0.0, 0.0), hi=(1.0, 1.0)):
+    """N x N generator mesh with interior nodes displaced by U(-0.1 h, 0.1 h)
+    (the commented-out perturbation of convergence_test.cpp:176-187)."""
+    mp, points, ptids = oracle.make_mesh(N, N, lo, hi)
+    rng = np.random.default_rng(seed)
+    h = (hi[0] - lo[0]) / N
+    d = rng.uniform(-0.1 * h, 0.1 * h, size=points.shape)
+    interior = np.ones(points.shape[0], dtype=bool)
+    ij = np.arange(points.shape[0])
+    i, j = ij % (N + 1), ij // (N + 1)
+    interior &= (i > 0) & (i < N) & (j > 0) & (j < N)
+    points[interior] += d[interior]
+    return points, ptids
+
+
+BATCH_CONFIGS = [
+    # (cd, fd, quad, stab)  -- the BASELINE.json configs and their neighbours
+    (2, 1, "tensor", "fancy"), (3, 2, "tensor", "fancy"), (4, 3, "tensor", "fancy"),
+    (0, 1, "tensor", "fancy"), (0, 0, "tensor", "fancy"), (1, 1, "tensor", "fancy"),
+    (2, 2, "tensor", "fancy"), (3, 3, "tensor", "fancy"), (1, 0, "tensor", "fancy"),
+    (1, 2, "tensor", "fancy"), (2, 3, "tensor", "fancy"),
+    (2, 1, "fan", "naive"), (3, 2, "fan", "naive"), (2, 1, "tensor", "naive"), (3, 2, "tensor", "naive"),
+    (1, 1, "fan", "fancy"), (2, 2, "fan", "fancy"), (0, 1, "fan", "fancy"),
+]
+
+
+@pytest.mark.parametrize("cd,fd,kind,stabname", BATCH_CONFIGS)
+def test_batch_matches_oracle(asm, oracle, cd, fd, kind, stabname):
+    import proton_amd as pa
+    from proton_amd.batch import to_rowcol
+    N = 13                                   # 169 cells: not a multiple of any cells-per-wavefront
+    points, ptids = perturbed_mesh(oracle, N, seed=1234 + cd * 10 + fd)
+    asm.set_mesh(points, ptids)
+    quad = pa.QUAD_TENSOR if kind == "tensor" else pa.QUAD_FAN
+    stab = pa.STAB_FANCY if stabname == "fancy" else pa.STAB_NAIVE
+    di = oracle.degrees(cd, fd)
+    st, ref = oracle.local_ops_batch(points, ptids, di, quad, stab, want=("oper", "data", "stab", "lc"))
+    assert st == 0
+    out = asm.local_ops(cd, fd, quad, stab, want=("oper", "data", "stab", "lc", "info"))
+    asm.synchronize()
+    assert int(out["info"].abs().max().cpu()) == 0
+    for k in ("oper", "data", "stab", "lc"):
+        assert nerr_cells(to_rowcol(out[k]), ref[k]) < TOL, k
+    # sub-range [first, first+n) with odd sizes
+    for first, n in ((0, 1), (5, 7), (160, 9), (3, 0)):
+        sub = asm.local_ops(cd, fd, quad, stab, first=first, n=n, want=("lc",))
+        if n:
+            assert nerr_cells(to_rowcol(sub["lc"]), ref["lc"][first:first + n]) < TOL
+    # rhs (utils.hpp:153-174) with f = 2 pi^2 sin sin, and with caller-sampled values
+    f = lambda x, y: 2.0 * math.pi ** 2 * math.sin(math.pi * x) * math.sin(math.pi * y)  # noqa: E731
+    st, refr = oracle.local_ops_batch(points, ptids, di, quad, pa.STAB_NONE, fn=f, want=())
+    rhs = asm.cell_rhs(cd, pa.capi.FN_SIN_SIN_RHS, quad)
+    assert nerr_cells(rhs.cpu().numpy()[:, :, None], refr["rhs"][:, :, None]) < TOL
+    xyw = asm.quadrature_points(2 * cd, quad)
+    import torch
+    fv = 2.0 * math.pi ** 2 * torch.sin(math.pi * xyw[:, :, 0]) * torch.sin(math.pi * xyw[:, :, 1])
+    rhs2 = asm.cell_rhs(cd, pa.capi.FN_SAMPLED, quad, fvals=fv.contiguous())
+    assert nerr_cells(rhs2.cpu().numpy()[:, :, None], refr["rhs"][:, :, None]) < TOL
+
+
+def test_error_codes(asm):
+    import ctypes as C
+    import proton_amd as pa
+    L = pa.capi.lib()
+    asm.generate_mesh(4, 4)
+    di, fell_back = pa.degree_info(7, 1)              # invalid pair reverts to equal order (utils.hpp:88-91)
+    assert fell_back and (di.cell_deg, di.face_deg) == (1, 1)
+    di, _ = pa.degree_info(4, 3)
+    assert L.pa_local_ops_batch(asm.ctx.h, di, pa.QUAD_FAN, pa.STAB_NAIVE, 0, 16, None, None, None, None, None) == 3
+    di5 = pa.DegreeInfo(5, 5, 6)                      # 2*recdeg = 12 needs golub_welsch
+    assert L.pa_local_ops_batch(asm.ctx.h, di5, pa.QUAD_TENSOR, pa.STAB_NAIVE, 0, 16, None, None, None, None, None) == 3
+    di, _ = pa.degree_info(3, 2)
+    assert L.pa_local_ops_batch(asm.ctx.h, di, pa.QUAD_TENSOR, pa.STAB_FANCY, 10, 7, None, None, None, None, None) == 1
+    assert L.pa_local_ops_batch(asm.ctx.h, di, pa.QUAD_TENSOR, 9, 0, 16, None, None, None, None, None) == 1
+    # out-of-range point id is refused at upload (the kernels gather unchecked)
+    pts = np.zeros((4, 2)); ids = np.array([[0, 1, 2, 7]], dtype=np.uint32)
+    assert L.pa_mesh_upload(asm.ctx.h, pts.ctypes.data, 4, ids.ctypes.data, 1) == 1
+
+
+def test_degenerate_cell_reports_pivot(asm):
+    """A zero-area cell: Eigen's LLT would silently produce NaNs; the info word flags it."""
+    import proton_amd as pa
+    points = np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0], [3.0, 0.0]])
+    asm.set_mesh(points, np.array([[0, 1, 2, 3]], dtype=np.uint32))
+    out = asm.local_ops(2, 1, pa.QUAD_TENSOR, pa.STAB_NAIVE, want=("lc", "info"))
+    asm.synchronize()
+    assert int(out["info"].cpu()[0]) != 0
+
+
+def test_generated_mesh_matches_reference_generator(asm, oracle):
+    import torch
+    from proton_amd.batch import to_rowcol
+    import proton_amd as pa
+    N = 9
+    asm.generate_mesh(N, N, (-1.0, -1.0), (1.0, 1.0))       # obstacle.cpp:234-238 domain
+    mp, points, ptids = oracle.make_mesh(N, N, (-1.0, -1.0), (1.0, 1.0))
+    di = oracle.degrees(0, 1)
+    st, ref = oracle.local_ops_batch(points, ptids, di, pa.QUAD_TENSOR, pa.STAB_FANCY, want=("lc",))
+    out = asm.local_ops(0, 1, pa.QUAD_TENSOR, pa.STAB_FANCY, want=("lc",))
+    assert nerr_cells(to_rowcol(out["lc"]), ref["lc"]) < TOL
+    # row partition [3, 7): local cell 0 is global cell 3*N
+    asm.generate_mesh(N, N, (-1.0, -1.0), (1.0, 1.0), rows=(3, 7))
+    assert asm.ncells == 4 * N
+    out = asm.local_ops(0, 1, pa.QUAD_TENSOR, pa.STAB_FANCY, want=("lc",))
+    assert nerr_cells(to_rowcol(out["lc"]), ref["lc"][3 * N:7 * N]) < TOL
+
+
+@pytest.mark.parametrize("N,cd,fd", [(1024, 3, 2), (256, 2, 1), (512, 0, 1)])
+def test_full_size_properties(asm, oracle, N, cd, fd):
+    """BASELINE.json sizes: properties that do not need the oracle on every cell.
+    lc is symmetric, annihilates the interpolant of constants (cell dofs (1,0..), face dofs (1,0..)),
+    and on the uniform generator mesh every cell equals the oracle's cell 0 up to rounding."""
+    import torch
+    import proton_amd as pa
+    asm.generate_mesh(N, N)
+    out = asm.local_ops(cd, fd, pa.QUAD_TENSOR, pa.STAB_FANCY, want=("lc", "info"))
+    asm.synchronize()
+    lc = out["lc"]
+    assert int(out["info"].abs().max().cpu()) == 0
+    assert bool(torch.isfinite(lc).all())
+    scale = lc.abs().amax(dim=(1, 2))
+    assert float(((lc - lc.transpose(1, 2)).abs().amax(dim=(1, 2)) / scale).max()) < TOL
+    di = oracle.degrees(cd, fd)
+    one = torch.zeros(di.msize, dtype=torch.float64, device=lc.device)
+    one[0] = 1.0
+    for f in range(4):
+        one[di.cbs + f * di.fbs] = 1.0
+    assert float(((lc @ one).abs().amax(dim=1) / scale).max()) < 1e-11
+    mp, points, ptids = oracle.make_mesh(N, N)
+    st, ref = oracle.local_ops_batch(points, ptids, di, pa.QUAD_TENSOR, pa.STAB_FANCY, first=0, n=1, want=("lc",))
+    ref0 = torch.from_numpy(ref["lc"][0].T.copy()).to(lc.device)
+    err = (lc - ref0).abs().amax(dim=(1, 2)) / ref0.abs().max()
+    assert float(err.max()) < 1e-10        # coordinates i*h differ in the last bits from cell to cell
+    # a few scattered cells against the oracle proper
+    idx = [0, 1, N - 1, N * N // 2 + 17, N * N - 1]
+    for c in idx:
+        st, r = oracle.local_ops_batch(points, ptids, di, pa.QUAD_TENSOR, pa.STAB_FANCY, first=c, n=1, want=("lc",))
+        got = lc[c].cpu().numpy().T
+        assert nerr(got, r["lc"][0]) < TOL
