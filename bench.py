@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- cells assembled per second on an N x N quad mesh (BASELINE.json's metric).
+
+A "step" is one pass of the hot path over the whole mesh: for every cell the local operator
+lc = data + stab (make_hho_laplacian + make_hho_fancy_stabilization, hho.hpp:32-237) and the
+cell right-hand side (make_rhs, utils.hpp:153-174) are computed and written to HBM
+(mode L of BASELINE.md section 4: 8 msize^2 + 8 cbs + 80 algorithmic bytes per cell).
+Default workload: the north-star target, 1024 x 1024, k = 2 (hho_degree_info(3, 2)), tensor
+Gauss, fancy stabilization.  Inputs (the structured mesh) are generated on the device and are
+resident in HBM when the timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+With N > 1 the cell rows are block-partitioned over the ranks (strong scaling, same mesh) and
+every step ends with the exchange the north star names: static condensation of the cell dofs and
+an RCCL all_gather of the condensed face-dof blocks (values only; indices are closed-form).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WORKLOADS = {
+    # name: (N, cd, fd, quad, stab, domain lo, hi, rhs fn id, rhs dinc, source config)
+    "quad1024_k2": dict(N=1024, cd=3, fd=2, quad="tensor", stab="fancy", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0,
+                        note="north-star target: 1024x1024 quad_mesh, hho_degree_info(3,2), fancy stabilization"),
+    "quad256_k1_fan": dict(N=256, cd=2, fd=1, quad="fan", stab="naive", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0,
+                           note="configs[1]: cuthho_square -M 256 -N 256 -k 1 -f, uncut cells (fan quadrature, naive stabilization)"),
+    "quad512_k2_fan": dict(N=512, cd=3, fd=2, quad="fan", stab="naive", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0,
+                           note="configs[2] without the cut cells: 512x512 k=2 fan quadrature, naive stabilization"),
+    "obstacle512_k1": dict(N=512, cd=0, fd=1, quad="tensor", stab="fancy", lo=(-1.0, -1.0), hi=(1.0, 1.0), fn=3, dinc=1,
+                           note="configs[3]: apps/obstacle 512x512 k=1, hho_degree_info(0,1)"),
+    "quad2048_k3": dict(N=2048, cd=4, fd=3, quad="tensor", stab="fancy", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0,
+                        note="configs[4]: 2048x2048 k=3 Laplacian, hho_degree_info(4,3)"),
+    "quad1024_k1": dict(N=1024, cd=2, fd=1, quad="tensor", stab="fancy", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0,
+                        note="1024x1024 k=1"),
+    "quad1024_k3": dict(N=1024, cd=4, fd=3, quad="tensor", stab="fancy", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0,
+                        note="1024x1024 k=3"),
+}
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def bytes_per_cell(msize, cbs):
+    """Algorithmic bytes per cell, mode L (BASELINE.md section 4 / SURVEY.md section 8d):
+    lc written (8 msize^2) + cell rhs written (8 cbs) + 4 node coordinates (64) + 4 u32 ids (16)."""
+    return 8 * msize * msize + 8 * cbs + 80
+
+
+def row_partition(N, world, rank):
+    return (rank * N) // world, ((rank + 1) * N) // world
+
+
+def cpu_baseline(w, sample_rows):
+    """The oracle (CPU restatement, single thread like the reference) on a bounded sample of the
+    same workload: the first `sample_rows` cell rows of the same mesh."""
+    import oracle_lib
+    N = w["N"]
+    mp, points, ptids = oracle_lib.make_mesh(N, N, w["lo"], w["hi"])
+    di = oracle_lib.degrees(w["cd"], w["fd"])
+    quad = oracle_lib.QUAD_TENSOR if w["quad"] == "tensor" else oracle_lib.QUAD_FAN
+    stab = oracle_lib.STAB_FANCY if w["stab"] == "fancy" else oracle_lib.STAB_NAIVE
+    n = sample_rows * N
+    oracle_lib.local_ops_batch(points, ptids, di, quad, stab, first=0, n=min(n, 2048), fn=w["fn"], rhs_di=w["dinc"],
+                               want=("lc",))                       # warm-up
+    t0 = time.perf_counter()
+    st, _ = oracle_lib.local_ops_batch(points, ptids, di, quad, stab, first=0, n=n, fn=w["fn"], rhs_di=w["dinc"],
+                                       want=("lc",))
+    dt = time.perf_counter() - t0
+    assert st == 0
+    return {"value": n / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "first %d of %d cell rows (%d cells) of the same mesh, %.1f s, oracle/hho_oracle.c "
+                      "(-O3 -mavx, single thread like the reference)" % (sample_rows, N, n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="quad1024_k2", choices=sorted(WORKLOADS))
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "none"],
+                    help="N>1 only: all_gather of the condensed face-dof blocks at the end of every step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="cell rows timed by the CPU baseline (0 = auto, ~15 s)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import proton_amd as pa
+    from proton_amd.batch import BatchAssembler
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    w = WORKLOADS[args.workload]
+    N = w["N"]
+    quad = pa.QUAD_TENSOR if w["quad"] == "tensor" else pa.QUAD_FAN
+    stab = pa.STAB_FANCY if w["stab"] == "fancy" else pa.STAB_NAIVE
+    di, _ = pa.degree_info(w["cd"], w["fd"])
+    sz = pa.sizes_for(di, quad)
+    asm = BatchAssembler(local_rank)
+    r0, r1 = row_partition(N, world, rank)
+    asm.generate_mesh(N, N, w["lo"], w["hi"], rows=(r0, r1))
+    n_local = asm.ncells
+    dev = asm.device
+
+    lc = torch.empty((n_local, sz.msize, sz.msize), dtype=torch.float64, device=dev)
+    rhs = torch.empty((n_local, sz.cbs), dtype=torch.float64, device=dev)
+    out = {"lc": lc}
+    exchange = world > 1 and args.exchange == "allgather"
+    if exchange:
+        nf = 4 * sz.fbs
+        per_cell = nf * nf + nf                     # S (values only) + g
+        counts = [(row_partition(N, world, r)[1] - row_partition(N, world, r)[0]) * N for r in range(world)]
+        gathered = [torch.empty(c * per_cell, dtype=torch.float64, device=dev) for c in counts]
+        mine = torch.empty(n_local * per_cell, dtype=torch.float64, device=dev)
+        S_view = mine[: n_local * nf * nf]
+        g_view = mine[n_local * nf * nf:]
+
+    k_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    k_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            k_start[i].record()
+        asm.local_ops(w["cd"], w["fd"], quad, stab, want=(), out=out)
+        if i is not None:
+            k_stop[i].record()
+        asm.cell_rhs(w["cd"], w["fn"], quad, dinc=w["dinc"], out=rhs)
+        if exchange:
+            asm.ctx.static_condensation(di, n_local, lc.data_ptr(), rhs.data_ptr(), S_view.data_ptr(), g_view.data_ptr(),
+                                        None, None)
+            dist.all_gather(gathered, mine)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in zip(k_start, k_stop)) / args.steps
+    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kern_ms = float(t[0]), float(t[1])
+
+    # sanity: the timed work produced finite local matrices (not a cached / skipped result)
+    probe = lc[:: max(1, n_local // 64)]
+    assert bool(torch.isfinite(probe).all()) and float(probe.abs().max()) > 0.0
+
+    if rank == 0:
+        total_cells = N * N
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_cells / (elapsed / args.steps)
+        bpc = bytes_per_cell(sz.msize, sz.cbs)
+        li = asm.ctx.launch_info(di, quad, stab, n_local)
+        achieved = n_local * bpc / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                rec = json.load(open(tf)).get(args.workload)
+                if rec and rec.get("n_gpus", 1) == world:
+                    traffic = rec["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "cells assembled/sec on N x N quad mesh (HHO local operators lc + cell rhs per cell)",
+            "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "mesh": "%dx%d quad_mesh on [%g,%g]^2 (reference generator)" % (N, N, w["lo"][0], w["hi"][0]),
+                       "hho_degree_info": [w["cd"], w["fd"]], "k": w["fd"], "quadrature": w["quad"], "stabilization": w["stab"],
+                       "cells": total_cells, "msize": sz.msize, "outputs": "lc (msize^2 f64) + cell rhs per cell, to HBM",
+                       "parallelism": "cell rows block-partitioned over %d GPU(s)" % world,
+                       "exchange": ("static condensation + RCCL all_gather of condensed face blocks (values)" if exchange else "none"),
+                       "note": w["note"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": li.kernel_name.decode(), "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_cell": bpc, "cells_per_launch": n_local,
+                         "lanes_per_cell": li.lanes_per_cell, "grid_blocks": li.grid_blocks,
+                         "lds_bytes_per_block": li.lds_bytes_per_block},
+            "kernel_only_cells_per_s": total_cells / (kern_ms * 1e-3) if world == 1 else n_local * world / (kern_ms * 1e-3),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            rows = args.cpu_sample_rows
+            if rows <= 0:       # ~15 s of single-thread CPU work, measured rate of the oracle: 60 / 18 / 105 us per cell
+                per_cell_us = {1: 18.0, 2: 60.0, 3: 105.0}.get(w["fd"], 60.0)
+                rows = max(1, min(N, int(15e6 / per_cell_us / N)))
+            res["cpu_baseline"] = cpu_baseline(w, rows)
+            res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,8 +76,11 @@ typedef struct {
 int pa_sizes_for(pa_degree_info di, int quad_kind, pa_sizes *out);
 
 /* ---- context ------------------------------------------------------------------------ */
-/* `stream` is a hipStream_t (NULL = the context creates and owns one). */
-int pa_context_create(int device, void *stream, pa_context **out);
+/* `stream` is the hipStream_t every call of the context is enqueued on; NULL is HIP's default
+ * (null) stream -- which is what torch.cuda.current_stream().cuda_stream reports for torch's
+ * default stream.  With own_stream != 0 `stream` is ignored and the context creates (and later
+ * destroys) a non-blocking stream of its own. */
+int pa_context_create(int device, void *stream, int own_stream, pa_context **out);
 int pa_context_destroy(pa_context *ctx);
 int pa_context_synchronize(pa_context *ctx);
 const char *pa_last_error(pa_context *ctx);      /* text of the last HIP failure, "" if none  */

@@ -611,6 +611,42 @@ int hho_make_fancy_stabilization(const double pts[8], const uint64_t ids[4], hho
 }
 
 /* ------------------------------------------------------------------ */
+/* driver lambdas                                                      */
+/* ------------------------------------------------------------------ */
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+static double fn_sin_sin_rhs(double x, double y, void *u) { (void)u; return 2.0 * M_PI * M_PI * sin(M_PI * x) * sin(M_PI * y); }
+static double fn_sin_sin_sol(double x, double y, void *u) { (void)u; return sin(M_PI * x) * sin(M_PI * y); }
+static double fn_obstacle_rhs(double x, double y, void *u)
+{
+    (void)u;
+    double r0 = 0.7, r = sqrt(x * x + y * y);
+    if (r > r0) return -16 * r * r + 8 * r0 * r0;
+    return -8.0 * (r0 * r0 * (r0 * r0 + 1)) + 8 * r0 * r0 * r * r;
+}
+static double fn_obstacle_sol(double x, double y, void *u)
+{
+    (void)u;
+    double r0 = 0.7, r = sqrt(x * x + y * y);
+    double s = r * r - r0 * r0, t = s > 0.0 ? s : 0.0;
+    return t * t;
+}
+static double fn_one(double x, double y, void *u) { (void)x; (void)y; (void)u; return 1.0; }
+
+hho_scalar_fn hho_builtin_fn(int id)
+{
+    switch (id) {
+    case 1: return fn_sin_sin_rhs;
+    case 2: return fn_sin_sin_sol;
+    case 3: return fn_obstacle_rhs;
+    case 4: return fn_obstacle_sol;
+    case 5: return fn_one;
+    default: return NULL;
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* utils.hpp:113-227                                                   */
 /* ------------------------------------------------------------------ */
 int hho_cell_mass_matrix(const double pts[8], int quad_kind, int degree, int di, double *mass)

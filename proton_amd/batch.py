@@ -21,8 +21,10 @@ class BatchAssembler:
             raise RuntimeError("proton_amd needs a GPU: torch.cuda.is_available() is False (no CPU fallback)")
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else None
-        self.ctx = capi.Context(device, stream)
+        if use_torch_stream:      # enqueue on torch's current stream (0 = the default stream)
+            self.ctx = capi.Context(device, torch.cuda.current_stream(self.device).cuda_stream)
+        else:
+            self.ctx = capi.Context(device, own_stream=True)
         self._keep = []
 
     # ---- mesh -----------------------------------------------------------------------

@@ -55,6 +55,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    if os.environ.get("PA_NO_TORCH_PRELOAD") != "1":
+        # torch bundles its own HIP/HSA runtime; two runtimes in one process cannot both open the
+        # device.  Import torch first so libproton_amd.so binds to the runtime torch already loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("proton_amd: %s is missing -- run `python -m proton_amd._build` "
                           "(there is no CPU fallback)" % LIB_PATH)
@@ -66,7 +73,7 @@ def lib():
     L.pa_degree_info_make.restype = DegreeInfo
     L.pa_degree_info_make.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.pa_sizes_for.argtypes = [DegreeInfo, C.c_int, C.POINTER(Sizes)]
-    L.pa_context_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.pa_context_create.argtypes = [C.c_int, vp, C.c_int, C.POINTER(vp)]
     L.pa_context_destroy.argtypes = [vp]
     L.pa_context_synchronize.argtypes = [vp]
     L.pa_last_error.argtypes = [vp]
@@ -104,12 +111,13 @@ def sizes_for(di, quad):
 
 
 class Context:
-    """RAII wrapper of pa_context.  `stream` is a raw hipStream_t handle (int) or None."""
+    """RAII wrapper of pa_context.  `stream` is a raw hipStream_t handle (int; 0/None = HIP's
+    default stream); own_stream=True lets the library create its own non-blocking stream."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, own_stream=False):
         self._L = lib()
         h = C.c_void_p()
-        st = self._L.pa_context_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        st = self._L.pa_context_create(device, C.c_void_p(stream) if stream else None, int(own_stream), C.byref(h))
         if st != 0:
             raise ProtonAmdError(st, "pa_context_create", "is a GPU visible?")
         self.h = h

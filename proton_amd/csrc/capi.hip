@@ -119,14 +119,16 @@ int pa_sizes_for(pa_degree_info di, int quad_kind, pa_sizes *out)
         if (n > 5) return PA_ERR_QUADRATURE;          // would need golub_welsch (quadratures.hpp:32-75)
         out->cell_qps = n * n;
     } else {
-        if (qdeg > 8) return PA_ERR_QUADRATURE;       // quadratures.hpp:245-246
+        // quadratures.hpp:245-246 throws above 8; degree 8 itself selects the empty rules[8]
+        // (quadratures_dunavant.hpp:129): zero points, singular gr_lhs, NaNs in the reference
+        if (qdeg > 8 || pa::dunavant_points(qdeg) == 0) return PA_ERR_QUADRATURE;
         out->cell_qps = 4 * pa::dunavant_points(qdeg);
     }
     out->face_qps = pa::gauss_nodes(2 * di.face_deg);
     return PA_OK;
 }
 
-int pa_context_create(int device, void *stream, pa_context **out)
+int pa_context_create(int device, void *stream, int own_stream, pa_context **out)
 {
     if (!out) return PA_ERR_INVALID_ARG;
     *out = nullptr;
@@ -135,7 +137,7 @@ int pa_context_create(int device, void *stream, pa_context **out)
     ctx->device = device;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) {
-        if (stream) { ctx->stream = (hipStream_t)stream; ctx->owns_stream = false; }
+        if (!own_stream) { ctx->stream = (hipStream_t)stream; ctx->owns_stream = false; }
         else { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); ctx->owns_stream = true; }
     }
     if (e == hipSuccess) {

@@ -112,6 +112,8 @@ def lib():
     L.hho_mesh_face_is_boundary.argtypes = [mpp, C.c_size_t, C.c_size_t, C.c_int]
     L.hho_local_ops_batch.argtypes = [dp, u64p, C.c_size_t, C.c_size_t, Degrees, C.c_int, C.c_int,
                                       SCALAR_FN, C.c_void_p, C.c_int, dp, dp, dp, dp, dp]
+    L.hho_builtin_fn.restype = SCALAR_FN
+    L.hho_builtin_fn.argtypes = [C.c_int]
     _LIB = L
     return L
 
@@ -231,7 +233,12 @@ def local_ops_batch(points, ptids, di, quad, stab, first=0, n=None, fn=None, rhs
             ptr[key] = _dp(bufs[key])
         else:
             ptr[key] = None
-    cb = SCALAR_FN(lambda x, y, u: fn(x, y)) if fn is not None else C.cast(None, SCALAR_FN)
+    if fn is None:
+        cb = C.cast(None, SCALAR_FN)
+    elif isinstance(fn, int):
+        cb = L.hho_builtin_fn(fn)          # C function: no Python callback per quadrature point
+    else:
+        cb = SCALAR_FN(lambda x, y, u: fn(x, y))
     rhs = np.zeros((n, cbs)) if fn is not None else None
     st = L.hho_local_ops_batch(_dp(points), _u64p(ptids), first, n, di, quad, stab, cb, None, rhs_di,
                                ptr["oper"], ptr["data"], ptr["stab"], ptr["lc"],
