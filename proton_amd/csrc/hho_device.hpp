@@ -16,11 +16,17 @@
 //     matrices are gathered from them -- term by term the same sums the reference forms;
 //   * the face basis evaluated at the face Gauss points is t_q^k exactly, so every face mass
 //     matrix is (|F|/2) M^ with one constant factorization shared by all faces of all cells;
-//   * data = gr_rhs^T (L L^T)^-1 gr_rhs = Y^T Y with Y = L^-1 gr_rhs;
-//   * B_F = M_F^-1 T_F - E_F (the reference's proj2 + proj3, hho.hpp:222-231) is block
-//     structured whenever T_F = [trace_F | 0]: always for the naive stabilization, and for the
-//     fancy one when celdeg == recdeg (then pi_T^k p_T^k v == p_T^k v, hho.hpp:184-190 cancels);
-//   * local-matrix entries are accumulated in registers and streamed to HBM, coalesced.
+//   * lane c of a cell owns COLUMN c of every msize-wide matrix (gr_rhs, Y, oper, T, U): uniform
+//     loops, broadcast LDS reads, no per-entry index arithmetic;
+//   * data = gr_rhs^T (L L^T)^-1 gr_rhs = Y^T Y with Y = L^-1 gr_rhs (forward substitution only);
+//   * stab = (1/h) sum_F B_F^T M_F B_F = U^T U with U_F = sqrt(|F|/2h) L^^T B_F, where
+//     B_F = M_F^-1 T_F - E_F is the reference's proj2 + proj3 (hho.hpp:222-231); T_F = [trace_F | 0]
+//     for the naive stabilization and for the fancy one when celdeg == recdeg (then
+//     pi_T^k p_T^k v == p_T^k v and hho.hpp:184-190 cancels);
+//   * lc = Z^T Z with Z = [Y; U]: one symmetric rank update, each lane forming the entries
+//     (c, c+d mod msize), d = 0..msize/2, mirrored through an LDS image of the matrix and
+//     streamed to HBM with coalesced 16-byte stores;
+//   * reciprocals and square roots are v_rcp/v_rsq seeds refined by Newton steps (<= 1 ulp).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -70,43 +76,36 @@ struct Cfg {
     static constexpr int PPL = cdiv(NP, G);                   // evaluation points per lane
     static constexpr int MPL = cdiv(NMOM, G);                 // moments per lane
     static constexpr int SPL = cdiv(RBS * RBS, G);            // stiffness entries per lane
-    static constexpr int EPL = cdiv(MS * MS, G);              // local-matrix entries per lane
+    static constexpr int ND = MS / 2 + 1;                     // rotations of the symmetric update
+    static constexpr bool HAS_STAB = STAB != STAB_NONE;
     static constexpr bool FANCY = STAB == STAB_FANCY, NAIVE = STAB == STAB_NAIVE;
-    // T_F = [trace_F | 0]: block-structured stabilization
-    static constexpr bool BLOCK_STAB = NAIVE || (FANCY && CD == RD);
-    static constexpr bool GENERAL_FANCY = FANCY && CD != RD;
-    static constexpr int TC = GENERAL_FANCY ? RBS : CBS;      // trace columns kept
+    static constexpr bool GENERAL_FANCY = FANCY && CD != RD;  // T_F is dense; otherwise T_F = [trace_F | 0]
+    static constexpr int ZR = NR + (HAS_STAB ? NF : 0);       // rows of Z = [Y; U]
+    static constexpr int ZS = ZR | 1;                         // odd column stride: conflict-free rotated reads
 
     // ---- LDS map (doubles, per cell) ------------------------------------------------
-    // region A: quadrature-point tables; dead after S3b
+    // region A: quadrature-point tables, moments, stiffness (its lower part becomes chol(gr_lhs))
     static constexpr int oWPX = 0;                            // NQ x NPW   w * bx^e
     static constexpr int oPY = oWPX + NQ * NPW;               // NQ x NPW   by^e
     static constexpr int oPHF = oPY + NQ * NPW;               // NFP x RBS  phi at face points
-    static constexpr int oDN = oPHF + NFP * RBS;              // NFP x NR   w * (grad phi . n)
-    static constexpr int endA = oDN + NFP * NR;
-    // region C (aliases A): stabilization temporaries
-    static constexpr int oPT = 0;                             // NF x CBS   blockdiag(M_F)^-1 trace   (block path)
-    static constexpr int oLM = 0;                             // CBS x CBS  chol(M1)                   (general fancy)
-    static constexpr int oPR1 = oLM + CBS * CBS;              // CBS x MS
-    static constexpr int oTB = oPR1 + CBS * MS;               // NF x MS    B
-    static constexpr int oMB = oTB + NF * MS;                 // NF x MS    M_F B
-    static constexpr int endC = GENERAL_FANCY ? oMB + NF * MS : (BLOCK_STAB ? NF * CBS : 0);
-    static constexpr int oB = imax(endA, endC);
-    // region B: lives for the whole cell
-    static constexpr int oMOM = oB;                           // NMOM moments
-    static constexpr int oST = oMOM + NMOM;                   // RBS x RBS  stiffness
-    static constexpr int oMA = oST + RBS * RBS;               // RBS x RBS  mass (general fancy)
-    static constexpr int oGR = oMA + (GENERAL_FANCY ? RBS * RBS : 0);   // NR x MS gr_rhs
-    static constexpr int oY = oGR + NR * MS;                  // NR x MS    Y = L^-1 gr_rhs
-    static constexpr int oOP = oY + NR * MS;                  // NR x MS    oper (general fancy only)
-    static constexpr int oLG = oOP + (GENERAL_FANCY ? NR * MS : 0);     // NR x NR chol(gr_lhs)
-    static constexpr int oFT = oLG + NR * NR;                 // NF x TC    face traces
-    static constexpr int LDS_PER_CELL = oFT + NF * TC;
+    static constexpr int oDN = oPHF + NFP * RBS;              // NFP x NR   (w_q/2) (grad phi . edge normal)
+    static constexpr int oMOM = oDN + NFP * NR;               // NMOM moments
+    static constexpr int oST = oMOM + NMOM;                   // RBS x RBS  stiffness; L in place
+    static constexpr int oMA = oST + RBS * RBS;               // RBS x RBS  mass; chol(M1) in place (general fancy)
+    static constexpr int oFT = oMA + (GENERAL_FANCY ? RBS * RBS : 0);   // NF x RBS  trace / (|F|/2) (general fancy)
+    static constexpr int oSU = oFT + (GENERAL_FANCY ? NF * RBS : 0);    // 4: sqrt(|F| / 2h)
+    static constexpr int endA = oSU + 4;
+    // the LDS image of the output matrix aliases region A (dead once Z is complete)
+    static constexpr int oOUT = 0;
+    static constexpr int sizeA = (imax(endA, MS * MS) + 1) & ~1;
+    static constexpr int oZ = sizeA;                          // ZS x MS
+    static constexpr int LDS_PER_CELL = (oZ + ZS * MS + 1) & ~1;
     // kernel-invariant face tables shared by the cells of a block
     static constexpr int oFB = CPW * LDS_PER_CELL;            // NFQ x FBS: t_q^k
-    static constexpr int oLF = oFB + NFQ * FBS;               // FBS x FBS: chol of M^ (reciprocal diagonal)
-    static constexpr int oMF = oLF + FBS * FBS;               // FBS x FBS: M^ = sum_q w t^(i+j)
-    static constexpr int LDS_DOUBLES = oMF + FBS * FBS;
+    static constexpr int oCW = oFB + NFQ * FBS;               // NFQ x FBS: w_q t_q^k
+    static constexpr int oLF = oCW + NFQ * FBS;               // FBS x FBS: chol of M^ = sum_q w t^(i+j) (reciprocal diagonal)
+    static constexpr int oLFT = oLF + FBS * FBS;              // FBS x FBS: L^^T (true diagonal)
+    static constexpr int LDS_DOUBLES = oLFT + FBS * FBS;
 };
 
 struct LocalOpsArgs {
@@ -129,7 +128,35 @@ __device__ __forceinline__ void mono_exps(int m, int &p, int &r)
     p = k - r;
 }
 
-__device__ __forceinline__ double rcp_sqrt(double d) { return 1.0 / sqrt(d); }
+// 1/sqrt(x), 1/x, sqrt(x) for x > 0: hardware seed (~2^-26) + two Newton steps, <= 1 ulp
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double t = x * y;
+        const double e = __builtin_fma(-t, y, 1.0);
+        y = __builtin_fma(0.5 * y, e, y);
+    }
+    return y;
+}
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = __builtin_fma(-x, y, 1.0);
+        y = __builtin_fma(y, e, y);
+    }
+    return y;
+}
+__device__ __forceinline__ double fast_sqrt(double x)
+{
+    const double y = fast_rsqrt(x);
+    const double s = x * y;
+    const double r = __builtin_fma(-s, s, x);
+    return __builtin_fma(0.5 * y, r, s);
+}
 
 // -------------------------------------------------------------------------------------
 // Cholesky of an N x N SPD matrix in LDS (column-major, leading dim LD, lower part used),
@@ -152,7 +179,7 @@ __device__ __forceinline__ int lds_cholesky(double *A, int l)
         for (int k = 0; k < j; ++k) s -= row[k] * A[j + k * LD];
         const double d = __shfl(s, j, G);
         if (!(d > 0.0) && !bad) bad = j + 1;
-        const double r = rcp_sqrt(d);
+        const double r = fast_rsqrt(d);
         row[j] = s * r;
         if (act && l >= j) A[i + j * LD] = (l == j) ? r : row[j];
         __syncthreads();
@@ -210,7 +237,8 @@ template <class C>
 __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
 {
     constexpr int G = C::G, RBS = C::RBS, CBS = C::CBS, FBS = C::FBS, MS = C::MS, NR = C::NR, NF = C::NF;
-    constexpr int NQ = C::NQ, NFQ = C::NFQ, NFP = C::NFP, NP = C::NP, RD = C::RD, NPW = C::NPW, TC = C::TC;
+    constexpr int NQ = C::NQ, NFQ = C::NFQ, NFP = C::NFP, NP = C::NP, RD = C::RD, NPW = C::NPW;
+    constexpr int ZS = C::ZS, ND = C::ND;
     static_assert(MS <= G, "one lane per local-matrix column");
     static_assert(RBS <= G && NF <= G, "one lane per row in the factorizations");
     static_assert(C::NQ > 0, "empty quadrature rule (the rules[8] hole)");
@@ -220,28 +248,34 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
     const int g = lane / G, l0 = lane % G;
     const int l = l0;
     double *S = smem + g * C::LDS_PER_CELL;
-    double *FB = smem + C::oFB, *LF = smem + C::oLF, *MF = smem + C::oMF;
+    double *FB = smem + C::oFB, *CW = smem + C::oCW, *LF = smem + C::oLF, *LFT = smem + C::oLFT;
     const QuadTables *__restrict__ tab = a.tab;
 
     // ---- kernel-invariant tables.  ep = 4 (base . (x - bar_F)) / h_F^2 (bases.hpp:269-272) equals
-    // the Gauss abscissa t on the segment, so phi_F(x_q) = t_q^k and M_F = (|F|/2) sum_q w_q t_q^(i+j).
+    // the Gauss abscissa t on the segment, so phi_F(x_q) = t_q^k and M_F = (|F|/2) M^,
+    // M^ = sum_q w_q t_q^(i+j) = L^ L^^T for every face of every cell.
     if (lane < NFQ * FBS) {
         const int q = lane / FBS, k = lane % FBS;
         const double t = tab->gauss_x[NFQ][q];
         double v = 1.0;
         for (int e = 0; e < k; ++e) v *= t;
         FB[q * FBS + k] = v;
+        CW[q * FBS + k] = tab->gauss_w[NFQ][q] * v;
     }
     __syncthreads();
     if (lane < FBS * FBS) {
         const int i = lane % FBS, j = lane / FBS;
         double s = 0.0;
-        for (int q = 0; q < NFQ; ++q) s += (tab->gauss_w[NFQ][q] * FB[q * FBS + i]) * FB[q * FBS + j];
-        MF[i + j * FBS] = s;
+        for (int q = 0; q < NFQ; ++q) s += CW[q * FBS + i] * FB[q * FBS + j];
         LF[i + j * FBS] = s;
     }
     __syncthreads();
     lds_cholesky<FBS, FBS, 64>(LF, lane);
+    if (lane < FBS * FBS) {
+        const int j = lane % FBS, k = lane / FBS;          // (L^^T)[j][k] = L^[k][j], j <= k
+        LFT[j + k * FBS] = j < k ? LF[k + j * FBS] : (j == k ? 1.0 / LF[k + k * FBS] : 0.0);
+    }
+    __syncthreads();
 
     // ---- per-lane, cell-invariant bookkeeping -------------------------------------------
     // reference coordinates of the evaluation points this lane owns
@@ -267,17 +301,18 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
         } else if (p < NP) {
             const int q = (p - NQ) % NFQ;
             r0[r] = tab->gauss_x[NFQ][q];
-            rw[r] = tab->gauss_w[NFQ][q];
+            rw[r] = 0.5 * tab->gauss_w[NFQ][q];
         }
     }
-    // moments owned by this lane: exponents (p, r)
-    int mom_pr[C::MPL];
+    // moments owned by this lane: LDS offsets of w bx^p and by^r
+    int mom_ox[C::MPL], mom_oy[C::MPL];
 #pragma unroll
     for (int t = 0; t < C::MPL; ++t) {
         const int mu = l + t * G;
         int p = 0, r = 0;
         if (mu < C::NMOM) mono_exps(mu, p, r);
-        mom_pr[t] = p | (r << 8);
+        mom_ox[t] = C::oWPX + p;
+        mom_oy[t] = C::oPY + r;
     }
     // stiffness entries owned by this lane: stiff(i,j) = ih^2 (a a' MOM(a+a'-2, b+b') + b b' MOM(a+a', b+b'-2))
     // packed as idx1 | idx2<<8 | c1<<16 | c2<<24   (bases.hpp:170-176 with hho.hpp:57-61)
@@ -297,11 +332,20 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
         }
         st_code[t] = code;
     }
+    // column role of this lane: cell column (c < CBS) or column kf of face fc
+    const bool is_col = l < MS, is_cellcol = l < CBS;
+    const int c0 = is_col ? l : 0;
+    const int fc = is_cellcol ? 0 : (c0 - CBS) / FBS, kf = is_cellcol ? 0 : (c0 - CBS) % FBS;
+    double fbq[NFQ], ufc[FBS];                  // t_q^kf ; column kf of L^^T
+#pragma unroll
+    for (int q = 0; q < NFQ; ++q) fbq[q] = FB[q * FBS + kf];
+#pragma unroll
+    for (int j = 0; j < FBS; ++j) ufc[j] = LFT[j + kf * FBS];
 
     const size_t stride = (size_t)gridDim.x * C::CPW;
     for (size_t base = (size_t)blockIdx.x * C::CPW; base < a.n; base += stride) {
-        // Re-derive the lane index opaquely per cell: otherwise LICM hoists every per-entry index
-        // computation of every stage out of the cell loop and the kernel spills.
+        // Re-derive the lane index opaquely per cell: otherwise LICM hoists the index computations
+        // of every stage out of the cell loop and the kernel spills.
         int l = l0;
         asm volatile("" : "+v"(l));
         const bool valid = base + g < a.n;
@@ -318,38 +362,43 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
         {
             const double ax = px1 - px0, ay = py1 - py0, bx = px2 - px0, by = py2 - py0;
             const double cx = px3 - px0, cy = py3 - py0;
-            const double d1 = (ax * by - ay * bx) / 2.0, d2 = (bx * cy - by * cx) / 2.0;
+            const double d1 = (ax * by - ay * bx) * 0.5, d2 = (bx * cy - by * cx) * 0.5;
             const double rx = (ax + bx) * d1 + (bx + cx) * d2, ry = (ay + by) * d1 + (by + cy) * d2;
-            const double den = d1 + d2;
-            barx = px0 + rx / (den * 3); bary = py0 + ry / (den * 3);
+            const double iden = fast_rcp((d1 + d2) * 3);
+            barx = px0 + rx * iden; bary = py0 + ry * iden;
         }
-        // edge vectors in cell (CCW) order and their lengths: faces, normals, diameter
+        // edge vectors in cell (CCW) order, squared lengths of edges and diagonals
         const double e0x = px1 - px0, e0y = py1 - py0, e1x = px2 - px1, e1y = py2 - py1;
         const double e2x = px3 - px2, e2y = py3 - py2, e3x = px0 - px3, e3y = py0 - py3;
-        const double len0 = sqrt(e0x * e0x + e0y * e0y), len1 = sqrt(e1x * e1x + e1y * e1y);
-        const double len2 = sqrt(e2x * e2x + e2y * e2y), len3 = sqrt(e3x * e3x + e3y * e3y);
-        double hT;                                  // diameter  basic_geom.hpp:288-305
+        const double s0 = e0x * e0x + e0y * e0y, s1 = e1x * e1x + e1y * e1y;
+        const double s2 = e2x * e2x + e2y * e2y, s3 = e3x * e3x + e3y * e3y;
+        double h2;                                  // diameter^2  basic_geom.hpp:288-305
         {
             const double d02x = px2 - px0, d02y = py2 - py0, d13x = px3 - px1, d13y = py3 - py1;
-            hT = fmax(fmax(len0, len1), fmax(len2, len3));
-            hT = fmax(hT, fmax(sqrt(d02x * d02x + d02y * d02y), sqrt(d13x * d13x + d13y * d13y)));
+            h2 = fmax(fmax(s0, s1), fmax(s2, s3));
+            h2 = fmax(h2, fmax(d02x * d02x + d02y * d02y, d13x * d13x + d13y * d13y));
         }
-        const double ihalf = 1.0 / (0.5 * hT);      // bx = (x - bar)/(h/2)  bases.hpp:98-99
-        const double ih = 2.0 / hT;                 // bases.hpp:142
-        double area;                                // measure  basic_geom.hpp:317-334
-        {
+        const double rh = fast_rsqrt(h2);           // 1 / h_T
+        const double ih = 2.0 * rh;                 // bx = (x - bar)/(h/2), ih = 2/h  bases.hpp:98-99,142
+        double hinv = rh;                           // fancy: h = cell diameter  hho.hpp:201
+        if (C::NAIVE) {                             // naive: h = cell area      hho.hpp:119, basic_geom.hpp:317-334
             const double ux = px1 - px0, uy = py1 - py0, vx = px2 - px0, vy = py2 - py0;
             const double wx = px3 - px0, wy = py3 - py0;
-            area = fabs(ux * vy - uy * vx) * 0.5 + fabs(vx * wy - vy * wx) * 0.5;
+            hinv = fast_rcp(fabs(ux * vy - uy * vx) * 0.5 + fabs(vx * wy - vy * wx) * 0.5);
         }
-        const double hs0 = 0.5 * len0, hs1 = 0.5 * len1, hs2 = 0.5 * len2, hs3 = 0.5 * len3;   // |F|/2: M_F = hs * M^
+        // lanes 0..3: sqrt(|F| / (2 h)) of local face l, shared through LDS
+        if (C::HAS_STAB && l < 4) {
+            const double sq = sel4(s0, s1, s2, s3, l);
+            const double len = sq * fast_rsqrt(sq);
+            S[C::oSU + l] = fast_sqrt(0.5 * len * hinv);
+        }
 
         // ================= S1: evaluation points ======================================
 #pragma unroll
         for (int r = 0; r < C::PPL; ++r) {
             const int p = l + r * G;
             if (p < NP) {
-                double x, y, w, nx = 0.0, ny = 0.0;
+                double x, y, w, wnx = 0.0, wny = 0.0;
                 const bool is_cell = p < NQ;
                 if (is_cell) {
                     if (C::QUAD == QUAD_TENSOR) {
@@ -368,7 +417,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                         const double ax = sel4(px0, px1, px2, px3, t), ay = sel4(py0, py1, py2, py3, t);
                         const double bx = sel4(px1, px2, px3, px0, t), by = sel4(py1, py2, py3, py0, t);
                         const double v0x = bx - ax, v0y = by - ay, v1x = barx - ax, v1y = bary - ay;
-                        const double tarea = fabs((v0x * v1y - v0y * v1x) / 2.0);      // quadratures.hpp:248-251
+                        const double tarea = fabs((v0x * v1y - v0y * v1x) * 0.5);      // quadratures.hpp:248-251
                         x = ax * r0[r] + bx * r1[r] + barx * r2[r];
                         y = ay * r0[r] + by * r1[r] + bary * r2[r];
                         w = tarea * rw[r];
@@ -378,17 +427,17 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                     const double ax = sel4(px0, px1, px2, px3, f), ay = sel4(py0, py1, py2, py3, f);
                     const double bx = sel4(px1, px2, px3, px0, f), by = sel4(py1, py2, py3, py0, f);
                     const uint32_t ia = sel4u(idv.x, idv.y, idv.z, idv.w, f), ib = sel4u(idv.y, idv.z, idv.w, idv.x, f);
-                    const double ex = sel4(e0x, e1x, e2x, e3x, f), ey = sel4(e0y, e1y, e2y, e3y, f);   // edge in cell order
-                    const double len = sel4(len0, len1, len2, len3, f);
-                    nx = ey / len; ny = -ex / len;                // outward normal  basic_geom.hpp:361-369
+                    // w n = (w_q |F|/2) (e_y, -e_x)/|F|: the edge length cancels  (basic_geom.hpp:361-369,
+                    // quadratures.hpp:426); rw holds w_q / 2
+                    wnx = rw[r] * (by - ay); wny = -rw[r] * (bx - ax);
                     // the face runs from its LOWER-id endpoint (basic_geom.hpp:202-203, bases.hpp:260-261):
                     // its q-th point sits at -t_q in cell order when the ids are descending
                     const double t = (ia > ib) ? -r0[r] : r0[r];
                     x = 0.5 * (1 - t) * ax + 0.5 * (1 + t) * bx;   // quadratures.hpp:420-428
                     y = 0.5 * (1 - t) * ay + 0.5 * (1 + t) * by;
-                    w = rw[r] * len * 0.5;
+                    w = 0.0;
                 }
-                const double bx_ = (x - barx) * ihalf, by_ = (y - bary) * ihalf;
+                const double bx_ = (x - barx) * ih, by_ = (y - bary) * ih;
                 if (is_cell) {
                     // w * bx^e and by^e, e = 0..2 recdeg: the factors of every cell moment
                     double vx = w, vy = 1.0;
@@ -399,12 +448,13 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                         vx *= bx_; vy *= by_;
                     }
                 } else {
-                    // scaled monomials and normal derivatives at a face point  bases.hpp:93-184, hho.hpp:77-83
+                    // scaled monomials and weighted normal derivatives at a face point  bases.hpp:93-184, hho.hpp:77-83
                     const int pf = p - NQ;
                     double pwx[RD + 1], pwy[RD + 1];
                     pwx[0] = 1.0; pwy[0] = 1.0;
 #pragma unroll
                     for (int e = 1; e <= RD; ++e) { pwx[e] = pwx[e - 1] * bx_; pwy[e] = pwy[e - 1] * by_; }
+                    const double gnx = ih * wnx, gny = ih * wny;
                     int m = 0;
 #pragma unroll
                     for (int kk = 0; kk <= RD; ++kk) {
@@ -413,9 +463,9 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                             const int ex_ = kk - ii, ey_ = ii;      // (px,py) = (k-i, i)  bases.hpp:119-120
                             S[C::oPHF + pf * RBS + m] = pwx[ex_] * pwy[ey_];
                             if (m > 0) {
-                                const double gx = ex_ == 0 ? 0.0 : (ex_ * ih) * pwx[ex_ > 0 ? ex_ - 1 : 0] * pwy[ey_];
-                                const double gy = ey_ == 0 ? 0.0 : (ey_ * ih) * pwx[ex_] * pwy[ey_ > 0 ? ey_ - 1 : 0];
-                                S[C::oDN + pf * NR + (m - 1)] = w * (gx * nx + gy * ny);
+                                const double gx = ex_ == 0 ? 0.0 : (ex_ * gnx) * pwx[ex_ > 0 ? ex_ - 1 : 0] * pwy[ey_];
+                                const double gy = ey_ == 0 ? 0.0 : (ey_ * gny) * pwx[ex_] * pwy[ey_ > 0 ? ey_ - 1 : 0];
+                                S[C::oDN + pf * NR + (m - 1)] = gx + gy;
                             }
                         }
                     }
@@ -424,35 +474,14 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
         }
         __syncthreads();
 
-        // ================= S2: cell moments, face traces ==============================
+        // ================= S2: cell moments ===========================================
 #pragma unroll
         for (int t = 0; t < C::MPL; ++t) {
-            const int mu = l + t * G;
-            if (mu < C::NMOM) {
-                const int p = mom_pr[t] & 0xff, r = mom_pr[t] >> 8;
+            if (l + t * G < C::NMOM) {
                 double s = 0.0;
-#pragma unroll 4
-                for (int q = 0; q < NQ; ++q) s += S[C::oWPX + q * NPW + p] * S[C::oPY + q * NPW + r];
-                S[C::oMOM + mu] = s;
-            }
-        }
-        // FT[fk][m] = sum_q (w_q |F|/2 t_q^k) phi_m(x_fq)   hho.hpp:209-216 / 133-140.
-        // Point q of face f IS the reference's q-th face point (S1 mirrors t for faces whose lower-id
-        // endpoint comes second), so its face-basis value is t_q^k for either orientation.
-        if (C::STAB != STAB_NONE) {
-            constexpr int NE = NF * TC;
 #pragma unroll
-            for (int e0 = 0; e0 < NE; e0 += G) {
-                const int e = e0 + l;
-                if (e < NE) {
-                    const int m = e / NF, fk = e % NF, f = fk / FBS, k = fk % FBS;
-                    const double hs = sel4(hs0, hs1, hs2, hs3, f);
-                    double s = 0.0;
-#pragma unroll
-                    for (int q = 0; q < NFQ; ++q)
-                        s += (tab->gauss_w[NFQ][q] * hs * FB[q * FBS + k]) * S[C::oPHF + (f * NFQ + q) * RBS + m];
-                    S[C::oFT + fk + m * NF] = s;
-                }
+                for (int q = 0; q < NQ; ++q) s += S[mom_ox[t] + q * NPW] * S[mom_oy[t] + q * NPW];
+                S[C::oMOM + l + t * G] = s;
             }
         }
         __syncthreads();
@@ -471,225 +500,192 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                 }
             }
             if (C::GENERAL_FANCY) {
-#pragma unroll
-                for (int e0 = 0; e0 < RBS * RBS; e0 += G) {
-                    const int e = e0 + l;
-                    if (e < RBS * RBS) {
-                        int ai, bi, aj, bj;
-                        mono_exps(e % RBS, ai, bi);
-                        mono_exps(e / RBS, aj, bj);
-                        S[C::oMA + e] = S[C::oMOM + mono_index(ai + aj, bi + bj)];
-                    }
+                for (int e = l; e < RBS * RBS; e += G) {
+                    int ai, bi, aj, bj;
+                    mono_exps(e % RBS, ai, bi);
+                    mono_exps(e / RBS, aj, bj);
+                    S[C::oMA + e] = S[C::oMOM + mono_index(ai + aj, bi + bj)];
                 }
             }
         }
         __syncthreads();
 
-        // ================= S3b: gr_rhs, gr_lhs  hho.hpp:63-85 =========================
-        {
-            constexpr int NE = NR * MS;
+        // ================= S3b: column c of gr_rhs  hho.hpp:64-85 =====================
+        const int c = l < MS ? l : 0;
+        double col[NR];
+        if (l < CBS) {
 #pragma unroll
-            for (int e0 = 0; e0 < NE; e0 += G) {
-                const int e = e0 + l;
-                if (e < NE) {
-                    const int i = e % NR, j = e / NR;
-                    double s;
-                    if (j < CBS) {
-                        s = S[C::oST + (i + 1) + j * RBS];
-#pragma unroll 4
-                        for (int pf = 0; pf < NFP; ++pf) s -= S[C::oDN + pf * NR + i] * S[C::oPHF + pf * RBS + j];
-                    } else {
-                        const int f = (j - CBS) / FBS, k = (j - CBS) % FBS;
-                        s = 0.0;
+            for (int i = 0; i < NR; ++i) col[i] = S[C::oST + (i + 1) + c * RBS];
 #pragma unroll
-                        for (int q = 0; q < NFQ; ++q) s += S[C::oDN + (f * NFQ + q) * NR + i] * FB[q * FBS + k];
-                    }
-                    S[C::oGR + i + j * NR] = s;
-                }
+            for (int pf = 0; pf < NFP; ++pf) {
+                const double ph = S[C::oPHF + pf * RBS + c];
+#pragma unroll
+                for (int i = 0; i < NR; ++i) col[i] -= S[C::oDN + pf * NR + i] * ph;
             }
+        } else {
 #pragma unroll
-            for (int e0 = 0; e0 < NR * NR; e0 += G) {
-                const int e = e0 + l;
-                if (e < NR * NR) S[C::oLG + e] = S[C::oST + (e % NR + 1) + (e / NR + 1) * RBS];
+            for (int i = 0; i < NR; ++i) col[i] = 0.0;
+#pragma unroll
+            for (int q = 0; q < NFQ; ++q) {
+                const int ob = C::oDN + (fc * NFQ + q) * NR;
+#pragma unroll
+                for (int i = 0; i < NR; ++i) col[i] += S[ob + i] * fbq[q];
+            }
+        }
+        // trace columns / (|F|/2):  tr[fk] = sum_q w_q t_q^k phi_c(x_fq)   hho.hpp:209-216 / 133-140.
+        // Point q of face f IS the reference's q-th face point (S1 mirrors t for faces whose lower-id
+        // endpoint comes second), so its face-basis value is t_q^k for either orientation.
+        double ucol[C::HAS_STAB ? NF : 1];
+        if (C::HAS_STAB) {
+            constexpr int TCOLS = C::GENERAL_FANCY ? RBS : CBS;
+            const int m = l < TCOLS ? l : 0;
+#pragma unroll
+            for (int r = 0; r < NF; ++r) ucol[r] = 0.0;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int q = 0; q < NFQ; ++q) {
+                    const double ph = S[C::oPHF + (f * NFQ + q) * RBS + m];
+#pragma unroll
+                    for (int k = 0; k < FBS; ++k) ucol[f * FBS + k] += CW[q * FBS + k] * ph;
+                }
+            if (C::GENERAL_FANCY && l < RBS) {
+#pragma unroll
+                for (int r = 0; r < NF; ++r) S[C::oFT + r + m * NF] = ucol[r];
             }
         }
         __syncthreads();
 
-        // ================= S4/S5: L L^T = gr_lhs ; Y = L^-1 gr_rhs ; oper = L^-T Y  hho.hpp:92
-        int bad = lds_cholesky<NR, NR, G>(S + C::oLG, l);
-        {
-            double xcol[NR];
-            const int c = l < MS ? l : 0;
+        // ================= S4/S5: L L^T = gr_lhs (in place in ST[1:,1:]) ; Y = L^-1 gr_rhs  hho.hpp:63,92
+        double *LG = S + C::oST + 1 + RBS;
+        int bad = lds_cholesky<NR, RBS, G>(LG, l);
+        lds_forward<NR, RBS>(LG, col);
+        if (l < MS) {
 #pragma unroll
-            for (int k = 0; k < NR; ++k) xcol[k] = S[C::oGR + k + c * NR];
-            lds_forward<NR, NR>(S + C::oLG, xcol);
-            if (l < MS) {
+            for (int k = 0; k < NR; ++k) S[C::oZ + k + c * ZS] = col[k];
+        }
+        double ycol[NR];
 #pragma unroll
-                for (int k = 0; k < NR; ++k) S[C::oY + k + c * NR] = xcol[k];
-            }
-            if (C::GENERAL_FANCY || a.oper != nullptr) {
-                lds_backward<NR, NR>(S + C::oLG, xcol);
-                if (C::GENERAL_FANCY && l < MS) {
+        for (int k = 0; k < NR; ++k) ycol[k] = col[k];
+        if (C::GENERAL_FANCY || a.oper != nullptr) {
+            lds_backward<NR, RBS>(LG, col);                 // col = oper[:, c]
+            if (a.oper != nullptr && valid && l < MS) {
+                double *dst = a.oper + (cell - a.first) * (size_t)(NR * MS) + (size_t)c * NR;
 #pragma unroll
-                    for (int k = 0; k < NR; ++k) S[C::oOP + k + c * NR] = xcol[k];
-                }
-                if (a.oper != nullptr && valid && l < MS) {
-                    double *dst = a.oper + (cell - a.first) * (size_t)(NR * MS) + (size_t)c * NR;
-#pragma unroll
-                    for (int k = 0; k < NR; ++k) dst[k] = xcol[k];
-                }
+                for (int k = 0; k < NR; ++k) dst[k] = col[k];
             }
         }
-        __syncthreads();
 
-        // ================= S6: data = gr_rhs^T oper = Y^T Y  hho.hpp:93 ===============
-        double acc_d[C::EPL], acc_s[C::EPL];
-#pragma unroll
-        for (int t = 0; t < C::EPL; ++t) {
-            const int e = l + t * G;
-            const int i = e < MS * MS ? e % MS : 0, j = e < MS * MS ? e / MS : 0;
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < NR; ++k) s += S[C::oY + k + i * NR] * S[C::oY + k + j * NR];
-            asm volatile("" : "+v"(s));          // pin: keeps the FMAs next to their LDS reads (no sinking to S8)
-            acc_d[t] = s;
-            acc_s[t] = 0.0;
-        }
-
-        // ================= S7: stabilization =========================================
-        if (C::BLOCK_STAB) {
-            // B_F = [ M_F^-1 trace_F | -E_F ]  =>  (1/h) sum_F B_F^T M_F B_F =
-            //   (1/h) [ sum_F tr_F^T M_F^-1 tr_F   -tr^T ;  -tr   blockdiag(M_F) ]
-            {
-                const int c = l < CBS ? l : 0;
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    double xf[FBS];
-#pragma unroll
-                    for (int k = 0; k < FBS; ++k) xf[k] = S[C::oFT + (f * FBS + k) + c * NF];
-                    lds_forward<FBS, FBS>(LF, xf);
-                    lds_backward<FBS, FBS>(LF, xf);
-                    const double ihs = 1.0 / (f == 0 ? hs0 : f == 1 ? hs1 : f == 2 ? hs2 : hs3);
-                    if (l < CBS) {
-#pragma unroll
-                        for (int k = 0; k < FBS; ++k) S[C::oPT + (f * FBS + k) + c * NF] = xf[k] * ihs;
-                    }
-                }
-            }
-            __syncthreads();
-            const double hinv = 1.0 / (C::FANCY ? hT : area);      // hho.hpp:201 / hho.hpp:119
-#pragma unroll
-            for (int t = 0; t < C::EPL; ++t) {
-                const int e = l + t * G;
-                const int i = e < MS * MS ? e % MS : 0, j = e < MS * MS ? e / MS : 0;
-                double s = 0.0;
-                if (i < CBS && j < CBS) {
-#pragma unroll
-                    for (int r = 0; r < NF; ++r) s += S[C::oFT + r + i * NF] * S[C::oPT + r + j * NF];
-                } else if (i < CBS) {
-                    s = -S[C::oFT + (j - CBS) + i * NF];
-                } else if (j < CBS) {
-                    s = -S[C::oFT + (i - CBS) + j * NF];
-                } else {
-                    const int fi = (i - CBS) / FBS, fj = (j - CBS) / FBS;
-                    if (fi == fj) s = sel4(hs0, hs1, hs2, hs3, fi) * MF[(i - CBS) % FBS + ((j - CBS) % FBS) * FBS];
-                }
-                s *= hinv;
-                asm volatile("" : "+v"(s));
-                acc_s[t] = s;
-            }
-        } else if (C::GENERAL_FANCY) {
-            // proj1 = [I 0] - M1^{-1} (M2 R)   hho.hpp:184-190
-#pragma unroll
-            for (int e0 = 0; e0 < CBS * CBS; e0 += G) {
-                const int e = e0 + l;
-                if (e < CBS * CBS) S[C::oLM + e] = S[C::oMA + (e % CBS) + (e / CBS) * RBS];
-            }
-            __syncthreads();
-            const int badm = lds_cholesky<CBS, CBS, G>(S + C::oLM, l);
-            if (badm && !bad) bad = 100 + badm;
-            const int c = l < MS ? l : 0;
-            {
-                double xcol[CBS];
+        // ================= S6: column c of U ==========================================
+        if (C::HAS_STAB) {
+            if (C::GENERAL_FANCY) {
+                // proj1[:, c] = e_c - M1^-1 (M2 R[:, c])   hho.hpp:184-190
+                double pr[CBS];
 #pragma unroll
                 for (int i = 0; i < CBS; ++i) {
                     double s = 0.0;
 #pragma unroll
-                    for (int k = 0; k < NR; ++k) s += S[C::oMA + i + (1 + k) * RBS] * S[C::oOP + k + c * NR];
-                    xcol[i] = s;
+                    for (int k = 0; k < NR; ++k) s += S[C::oMA + i + (1 + k) * RBS] * col[k];
+                    pr[i] = s;
                 }
-                lds_forward<CBS, CBS>(S + C::oLM, xcol);
-                lds_backward<CBS, CBS>(S + C::oLM, xcol);
-                if (l < MS) {
+                __syncthreads();
+                const int badm = lds_cholesky<CBS, RBS, G>(S + C::oMA, l);
+                if (badm && !bad) bad = 100 + badm;
+                lds_forward<CBS, RBS>(S + C::oMA, pr);
+                lds_backward<CBS, RBS>(S + C::oMA, pr);
 #pragma unroll
-                    for (int i = 0; i < CBS; ++i) S[C::oPR1 + i + c * CBS] = (i == c ? 1.0 : 0.0) - xcol[i];
-                }
-            }
-            __syncthreads();
-            // column c of T_F = MR1 R + MR2 proj1 (hho.hpp:222-230; piKF.solve is linear), B = M_F^-1 T - E
+                for (int i = 0; i < CBS; ++i) pr[i] = (i == c ? 1.0 : 0.0) - pr[i];
+                // T_F[:, c] / (|F|/2) = MR1 R[:, c] + MR2 proj1[:, c]   (hho.hpp:222-230; piKF.solve is linear)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                double xf[FBS];
-#pragma unroll
-                for (int k = 0; k < FBS; ++k) {
-                    const int r = f * FBS + k;
+                for (int r = 0; r < NF; ++r) {
                     double s = 0.0;
 #pragma unroll
-                    for (int kk = 0; kk < NR; ++kk) s += S[C::oFT + r + (1 + kk) * NF] * S[C::oOP + kk + c * NR];
+                    for (int k = 0; k < NR; ++k) s += S[C::oFT + r + (1 + k) * NF] * col[k];
 #pragma unroll
-                    for (int kk = 0; kk < CBS; ++kk) s += S[C::oFT + r + kk * NF] * S[C::oPR1 + kk + c * CBS];
-                    xf[k] = s;
+                    for (int k = 0; k < CBS; ++k) s += S[C::oFT + r + k * NF] * pr[k];
+                    ucol[r] = s;
                 }
+            } else if (l >= CBS) {
+#pragma unroll
+                for (int r = 0; r < NF; ++r) ucol[r] = 0.0;     // T_F = [trace_F | 0]
+            }
+            // U_F = sqrt(|F|/2h) ( L^^-1 T_F/(|F|/2) - L^^T E_F )
+            const double4 su4 = *reinterpret_cast<const double4 *>(S + C::oSU);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const double su = f == 0 ? su4.x : f == 1 ? su4.y : f == 2 ? su4.z : su4.w;
+                double xf[FBS];
+#pragma unroll
+                for (int k = 0; k < FBS; ++k) xf[k] = ucol[f * FBS + k];
                 lds_forward<FBS, FBS>(LF, xf);
-                lds_backward<FBS, FBS>(LF, xf);
-                const double hs = f == 0 ? hs0 : f == 1 ? hs1 : f == 2 ? hs2 : hs3, ihs = 1.0 / hs;
 #pragma unroll
                 for (int k = 0; k < FBS; ++k) {
-                    double b = xf[k] * ihs;
-                    if (c == CBS + f * FBS + k) b -= 1.0;             // - I_F  hho.hpp:226
-                    xf[k] = b;
+                    const double e = (l >= CBS && fc == f) ? ufc[k] : 0.0;      // (L^^T E_F)[k][c]
+                    ucol[f * FBS + k] = su * (xf[k] - e);
                 }
-                if (l < MS) {
+            }
+            if (l < MS) {
 #pragma unroll
-                    for (int k = 0; k < FBS; ++k) {
-                        double mb = 0.0;
+                for (int r = 0; r < NF; ++r) S[C::oZ + NR + r + c * ZS] = ucol[r];
+            }
+        }
+        __syncthreads();
+
+        // ================= S7: lc = Z^T Z, entries (c, c + d mod MS) ==================
+        double acc_d[ND], acc_s[ND];
+        {
+            int cp = c;
 #pragma unroll
-                        for (int k2 = 0; k2 < FBS; ++k2) mb += MF[k + k2 * FBS] * xf[k2];
-                        S[C::oTB + (f * FBS + k) + c * NF] = xf[k];
-                        S[C::oMB + (f * FBS + k) + c * NF] = hs * mb;
-                    }
+            for (int d = 0; d < ND; ++d) {
+                const double *zc = S + C::oZ + cp * ZS;
+                double s = 0.0, u = 0.0;
+#pragma unroll
+                for (int k = 0; k < NR; ++k) s += ycol[k] * zc[k];
+                if (C::HAS_STAB) {
+#pragma unroll
+                    for (int r = 0; r < NF; ++r) u += ucol[r] * zc[NR + r];
+                }
+                asm volatile("" : "+v"(s), "+v"(u));     // pin: keep the FMAs next to their LDS reads
+                acc_d[d] = s; acc_s[d] = u;
+                cp = (cp + 1 == MS) ? 0 : cp + 1;
+            }
+        }
+        __syncthreads();      // every read of L (region A) and Z is done: region A becomes the output image
+
+        // ================= S8: mirror through LDS, stream to HBM ======================
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            double *dst = which == 0 ? a.lc : which == 1 ? a.data : a.stab;
+            if (dst == nullptr) continue;
+            if (l < MS) {
+                int cp = c;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    const double v = which == 0 ? acc_d[d] + acc_s[d] : which == 1 ? acc_d[d] : acc_s[d];
+                    S[C::oOUT + c + cp * MS] = v;
+                    S[C::oOUT + cp + c * MS] = v;
+                    cp = (cp + 1 == MS) ? 0 : cp + 1;
                 }
             }
             __syncthreads();
-            const double hinv = 1.0 / hT;                              // hho.hpp:201,233
+            if (valid) {
+                double *o = dst + (cell - a.first) * (size_t)(MS * MS);
+                constexpr int NPAIR = MS * MS / 2;
 #pragma unroll
-            for (int t = 0; t < C::EPL; ++t) {
-                const int e = l + t * G;
-                const int i = e < MS * MS ? e % MS : 0, j = e < MS * MS ? e / MS : 0;
-                double s = 0.0;
-#pragma unroll
-                for (int r = 0; r < NF; ++r) s += S[C::oTB + r + i * NF] * S[C::oMB + r + j * NF];
-                s *= hinv;
-                asm volatile("" : "+v"(s));
-                acc_s[t] = s;
-            }
-        }
-
-        // ================= S8: stream the local matrices to HBM =======================
-        if (valid) {
-            const size_t off = (cell - a.first) * (size_t)(MS * MS);
-#pragma unroll
-            for (int t = 0; t < C::EPL; ++t) {
-                const int e = l + t * G;
-                if (e < MS * MS) {
-                    if (a.lc != nullptr) a.lc[off + e] = acc_d[t] + acc_s[t];
-                    if (a.data != nullptr) a.data[off + e] = acc_d[t];
-                    if (a.stab != nullptr) a.stab[off + e] = acc_s[t];
+                for (int e0 = 0; e0 < NPAIR; e0 += G) {
+                    const int e = e0 + l;
+                    if (e < NPAIR) {
+                        const double2 v = *reinterpret_cast<const double2 *>(S + C::oOUT + 2 * e);
+                        *reinterpret_cast<double2 *>(o + 2 * e) = v;
+                    }
+                }
+                if ((MS * MS) & 1) {
+                    if (l == 0) o[MS * MS - 1] = S[C::oOUT + MS * MS - 1];
                 }
             }
-            if (a.info != nullptr && l == 0) a.info[cell - a.first] = bad;
+            __syncthreads();
         }
-        __syncthreads();      // region A is rewritten by the next cell
+        if (valid && a.info != nullptr && l == 0) a.info[cell - a.first] = bad;
     }
 }
 
