@@ -145,6 +145,7 @@ int pa_context_create(int device, void *stream, int own_stream, pa_context **out
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
         pa::fill_gauss(ctx->host_tab);
         pa::fill_dunavant(ctx->host_tab);
+        pa::fill_face_tables(ctx->host_tab);
         e = hipMalloc((void **)&ctx->d_tab, sizeof(pa::QuadTables));
     }
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tab, &ctx->host_tab, sizeof(pa::QuadTables), hipMemcpyHostToDevice);

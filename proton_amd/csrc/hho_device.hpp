@@ -32,6 +32,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifdef PA_MARKERS
+#define PA_MARK(x) asm volatile("; PAMARK " x)
+#else
+#define PA_MARK(x)
+#endif
 namespace pa {
 
 enum { QUAD_TENSOR = 0, QUAD_FAN = 1 };
@@ -40,11 +45,20 @@ enum { STAB_NONE = 0, STAB_NAIVE = 1, STAB_FANCY = 2 };
 // Quadrature tables, filled by the host (quad_tables.hpp) and passed by device pointer:
 //   gauss_*[n][i]: the n-node rule of gauss_legendre() in the reference's emission order;
 //   dun[r][row] = (l0, l1, l2, w) of dunavant rules[r] (0-based, rules[r] == rule_{r+1}).
+// Face tables for face degree fd (n = fd + 1 Gauss points, fbs = fd + 1 modes): the face basis at
+// the Gauss points is t_q^k, so M_F = (|F|/2) M^ with M^ = sum_q w_q t_q^(i+j) = L^ L^^T.
+struct FaceTables {
+    double fb[4][4];      // [q][k] t_q^k
+    double cw[4][4];      // [q][k] w_q t_q^k
+    double lf[4][4];      // [i][k] L^ (lower), diagonal holds 1 / L^[i][i]
+    double lft[4][4];     // [j][k] (L^^T)[j][k] = L^[k][j], j <= k
+};
 struct QuadTables {
     double gauss_x[6][5];
     double gauss_w[6][5];
     double dun[9][16][4];
     int dun_n[9];
+    FaceTables face[4];
 };
 
 __host__ __device__ constexpr int P2(int d) { return (d + 2) * (d + 1) / 2; }
@@ -80,32 +94,31 @@ struct Cfg {
     static constexpr bool HAS_STAB = STAB != STAB_NONE;
     static constexpr bool FANCY = STAB == STAB_FANCY, NAIVE = STAB == STAB_NAIVE;
     static constexpr bool GENERAL_FANCY = FANCY && CD != RD;  // T_F is dense; otherwise T_F = [trace_F | 0]
-    static constexpr int ZR = NR + (HAS_STAB ? NF : 0);       // rows of Z = [Y; U]
-    static constexpr int ZS = ZR | 1;                         // odd column stride: conflict-free rotated reads
 
-    // ---- LDS map (doubles, per cell) ------------------------------------------------
-    // region A: quadrature-point tables, moments, stiffness (its lower part becomes chol(gr_lhs))
+    // ---- LDS map (doubles, per cell).  Every vector that is read as a contiguous run starts at
+    // an even offset and has an even stride, so the reads are 16-byte ds_read_b128.
+    static constexpr int NRP = (NR + 1) & ~1;                 // padded row count of gr_lhs / Y
+    static constexpr int LD = (RBS + 1) & ~1;                 // stride of the (symmetric) stiffness matrix
+    static constexpr int ZR = NRP + (HAS_STAB ? NF : 0);      // rows of Z = [Y; pad; U]
+    static constexpr int ZS = ((ZR + 1) & ~1) % 4 == 2 ? ((ZR + 1) & ~1) : ((ZR + 1) & ~1) + 2;   // even, ZS/2 odd
     static constexpr int oWPX = 0;                            // NQ x NPW   w * bx^e
     static constexpr int oPY = oWPX + NQ * NPW;               // NQ x NPW   by^e
     static constexpr int oPHF = oPY + NQ * NPW;               // NFP x RBS  phi at face points
-    static constexpr int oDN = oPHF + NFP * RBS;              // NFP x NR   (w_q/2) (grad phi . edge normal)
-    static constexpr int oMOM = oDN + NFP * NR;               // NMOM moments
-    static constexpr int oST = oMOM + NMOM;                   // RBS x RBS  stiffness; L in place
-    static constexpr int oMA = oST + RBS * RBS;               // RBS x RBS  mass; chol(M1) in place (general fancy)
-    static constexpr int oFT = oMA + (GENERAL_FANCY ? RBS * RBS : 0);   // NF x RBS  trace / (|F|/2) (general fancy)
-    static constexpr int oSU = oFT + (GENERAL_FANCY ? NF * RBS : 0);    // 4: sqrt(|F| / 2h)
+    static constexpr int oDN = (oPHF + NFP * RBS + 1) & ~1;   // NFP x NRP  (w_q/2) (grad phi . edge normal)
+    static constexpr int oMOM = oDN + NFP * NRP;              // NMOM moments
+    // stiffness, stride LD; its [1:,1:] block becomes chol(gr_lhs) row by row: oST is odd so that
+    // the block (and every row of it) starts on a 16-byte boundary
+    static constexpr int oST = ((oMOM + NMOM) | 1);
+    static constexpr int oMA = (oST + LD * RBS + 1) & ~1;     // RBS x RBS  mass (general fancy); chol(M1) in place
+    static constexpr int oFT = oMA + (GENERAL_FANCY ? LD * RBS : 0);     // NF x RBS trace / (|F|/2) (general fancy)
+    static constexpr int oSU = (oFT + (GENERAL_FANCY ? NF * RBS : 0) + 1) & ~1;   // 4: sqrt(|F| / 2h)
     static constexpr int endA = oSU + 4;
     // the LDS image of the output matrix aliases region A (dead once Z is complete)
     static constexpr int oOUT = 0;
     static constexpr int sizeA = (imax(endA, MS * MS) + 1) & ~1;
     static constexpr int oZ = sizeA;                          // ZS x MS
     static constexpr int LDS_PER_CELL = (oZ + ZS * MS + 1) & ~1;
-    // kernel-invariant face tables shared by the cells of a block
-    static constexpr int oFB = CPW * LDS_PER_CELL;            // NFQ x FBS: t_q^k
-    static constexpr int oCW = oFB + NFQ * FBS;               // NFQ x FBS: w_q t_q^k
-    static constexpr int oLF = oCW + NFQ * FBS;               // FBS x FBS: chol of M^ = sum_q w t^(i+j) (reciprocal diagonal)
-    static constexpr int oLFT = oLF + FBS * FBS;              // FBS x FBS: L^^T (true diagonal)
-    static constexpr int LDS_DOUBLES = oLFT + FBS * FBS;
+    static constexpr int LDS_DOUBLES = CPW * LDS_PER_CELL;
 };
 
 struct LocalOpsArgs {
@@ -158,9 +171,51 @@ __device__ __forceinline__ double fast_sqrt(double x)
     return __builtin_fma(0.5 * y, r, s);
 }
 
+// 16-byte LDS read of two consecutive doubles (p is 16-byte aligned by construction of the LDS map)
+__device__ __forceinline__ double2 lds_pair(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+
+// s - sum_{k<N} p[k] x[k] with p a contiguous, 16-byte aligned LDS vector
+template <int N>
+__device__ __forceinline__ double lds_dotsub(double s, const double *p, const double *x)
+{
+#pragma unroll
+    for (int k = 0; k + 1 < N; k += 2) {
+        const double2 v = lds_pair(p + k);
+        s = __builtin_fma(-v.x, x[k], s);
+        s = __builtin_fma(-v.y, x[k + 1], s);
+    }
+    if (N & 1) s = __builtin_fma(-p[N - 1], x[N - 1], s);
+    return s;
+}
+// same with a count that is a constant after unrolling
+__device__ __forceinline__ double lds_dotsub_n(double s, const double *p, const double *x, int n)
+{
+#pragma unroll
+    for (int k = 0; k + 1 < n; k += 2) {
+        const double2 v = lds_pair(p + k);
+        s = __builtin_fma(-v.x, x[k], s);
+        s = __builtin_fma(-v.y, x[k + 1], s);
+    }
+    if (n & 1) s = __builtin_fma(-p[n - 1], x[n - 1], s);
+    return s;
+}
+template <int N>
+__device__ __forceinline__ double lds_dotadd(double s, const double *p, const double *x)
+{
+#pragma unroll
+    for (int k = 0; k + 1 < N; k += 2) {
+        const double2 v = lds_pair(p + k);
+        s = __builtin_fma(v.x, x[k], s);
+        s = __builtin_fma(v.y, x[k + 1], s);
+    }
+    if (N & 1) s = __builtin_fma(p[N - 1], x[N - 1], s);
+    return s;
+}
+
 // -------------------------------------------------------------------------------------
-// Cholesky of an N x N SPD matrix in LDS (column-major, leading dim LD, lower part used),
-// one lane per row.  L overwrites the lower triangle; the diagonal receives 1/L[j][j].
+// Cholesky of an N x N SPD matrix in LDS, one lane per row.  The matrix is symmetric and is
+// overwritten ROW-major: L[i][k] lands at A[i * LD + k] (rows contiguous and 16-byte aligned,
+// so every later use of a row is a run of ds_read_b128); the diagonal receives 1/L[j][j].
 // Returns 0 or 1+index of the first non-positive pivot (uniform over the G-lane group).
 // -------------------------------------------------------------------------------------
 template <int N, int LD, int G>
@@ -170,33 +225,34 @@ __device__ __forceinline__ int lds_cholesky(double *A, int l)
     const bool act = l < N;
     const int i = act ? l : 0;
 #pragma unroll
-    for (int k = 0; k < N; ++k) row[k] = A[i + k * LD];
+    for (int k = 0; k + 1 < N; k += 2) {
+        const double2 v = lds_pair(A + i * LD + k);
+        row[k] = v.x; row[k + 1] = v.y;
+    }
+    if (N & 1) row[N - 1] = A[i * LD + N - 1];
     int bad = 0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        double s = row[j];                 // A[i][j] - sum_{k<j} L[i][k] L[j][k]; row j's prefix is in LDS
-#pragma unroll
-        for (int k = 0; k < j; ++k) s -= row[k] * A[j + k * LD];
+        // A[i][j] - sum_{k<j} L[i][k] L[j][k]; row j's prefix is already in LDS
+        const double s = j == 0 ? row[0] : lds_dotsub_n(row[j], A + j * LD, row, j);
         const double d = __shfl(s, j, G);
         if (!(d > 0.0) && !bad) bad = j + 1;
         const double r = fast_rsqrt(d);
         row[j] = s * r;
-        if (act && l >= j) A[i + j * LD] = (l == j) ? r : row[j];
+        if (act && l >= j) A[i * LD + j] = (l == j) ? r : row[j];
         __syncthreads();
     }
     return bad;
 }
 
-// x <- L^-1 x (forward) and x <- L^-T x (backward); L as left by lds_cholesky.
+// x <- L^-1 x (forward) and x <- L^-T x (backward); L as left by lds_cholesky (row-major).
 template <int N, int LD>
 __device__ __forceinline__ void lds_forward(const double *L, double (&x)[N])
 {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        double s = x[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) s -= L[i + k * LD] * x[k];
-        x[i] = s * L[i + i * LD];
+        const double s = i == 0 ? x[0] : lds_dotsub_n(x[i], L + i * LD, x, i);
+        x[i] = s * L[i * LD + i];
     }
 }
 template <int N, int LD>
@@ -206,9 +262,30 @@ __device__ __forceinline__ void lds_backward(const double *L, double (&x)[N])
     for (int i = N - 1; i >= 0; --i) {
         double s = x[i];
 #pragma unroll
-        for (int k = i + 1; k < N; ++k) s -= L[k + i * LD] * x[k];
-        x[i] = s * L[i + i * LD];
+        for (int k = i + 1; k < N; ++k) s -= L[k * LD + i] * x[k];
+        x[i] = s * L[i * LD + i];
     }
+}
+
+// forward / backward substitution with the constant face factor L^ (uniform table reads)
+template <int FBS>
+__device__ __forceinline__ void face_forward(const FaceTables &ft, double (&x)[FBS])
+{
+#pragma unroll
+    for (int i = 0; i < FBS; ++i) {
+        double s = x[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= ft.lf[i][k] * x[k];
+        x[i] = s * ft.lf[i][i];
+    }
+}
+
+// force a wave-uniform double into scalar registers
+__device__ __forceinline__ double to_sgpr(double v)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
 // lane-dependent choice among four register values (kept as scalars: an array indexed this way
@@ -238,44 +315,27 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
 {
     constexpr int G = C::G, RBS = C::RBS, CBS = C::CBS, FBS = C::FBS, MS = C::MS, NR = C::NR, NF = C::NF;
     constexpr int NQ = C::NQ, NFQ = C::NFQ, NFP = C::NFP, NP = C::NP, RD = C::RD, NPW = C::NPW;
-    constexpr int ZS = C::ZS, ND = C::ND;
+    constexpr int ZS = C::ZS, ND = C::ND, NRP = C::NRP, LD = C::LD;
     static_assert(MS <= G, "one lane per local-matrix column");
     static_assert(RBS <= G && NF <= G, "one lane per row in the factorizations");
     static_assert(C::NQ > 0, "empty quadrature rule (the rules[8] hole)");
 
-    extern __shared__ double smem[];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     const int g = lane / G, l0 = lane % G;
     const int l = l0;
     double *S = smem + g * C::LDS_PER_CELL;
-    double *FB = smem + C::oFB, *CW = smem + C::oCW, *LF = smem + C::oLF, *LFT = smem + C::oLFT;
     const QuadTables *__restrict__ tab = a.tab;
-
-    // ---- kernel-invariant tables.  ep = 4 (base . (x - bar_F)) / h_F^2 (bases.hpp:269-272) equals
-    // the Gauss abscissa t on the segment, so phi_F(x_q) = t_q^k and M_F = (|F|/2) M^,
-    // M^ = sum_q w_q t_q^(i+j) = L^ L^^T for every face of every cell.
-    if (lane < NFQ * FBS) {
-        const int q = lane / FBS, k = lane % FBS;
-        const double t = tab->gauss_x[NFQ][q];
-        double v = 1.0;
-        for (int e = 0; e < k; ++e) v *= t;
-        FB[q * FBS + k] = v;
-        CW[q * FBS + k] = tab->gauss_w[NFQ][q] * v;
-    }
-    __syncthreads();
-    if (lane < FBS * FBS) {
-        const int i = lane % FBS, j = lane / FBS;
-        double s = 0.0;
-        for (int q = 0; q < NFQ; ++q) s += CW[q * FBS + i] * FB[q * FBS + j];
-        LF[i + j * FBS] = s;
-    }
-    __syncthreads();
-    lds_cholesky<FBS, FBS, 64>(LF, lane);
-    if (lane < FBS * FBS) {
-        const int j = lane % FBS, k = lane / FBS;          // (L^^T)[j][k] = L^[k][j], j <= k
-        LFT[j + k * FBS] = j < k ? LF[k + j * FBS] : (j == k ? 1.0 / LF[k + k * FBS] : 0.0);
-    }
-    __syncthreads();
+    // constant face tables, kept in scalar registers
+    FaceTables ft;
+#pragma unroll
+    for (int q = 0; q < NFQ; ++q)
+#pragma unroll
+        for (int k = 0; k < FBS; ++k) ft.cw[q][k] = to_sgpr(tab->face[C::FD].cw[q][k]);
+#pragma unroll
+    for (int i = 0; i < FBS; ++i)
+#pragma unroll
+        for (int k = 0; k <= i; ++k) ft.lf[i][k] = to_sgpr(tab->face[C::FD].lf[i][k]);
 
     // ---- per-lane, cell-invariant bookkeeping -------------------------------------------
     // reference coordinates of the evaluation points this lane owns
@@ -338,9 +398,9 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
     const int fc = is_cellcol ? 0 : (c0 - CBS) / FBS, kf = is_cellcol ? 0 : (c0 - CBS) % FBS;
     double fbq[NFQ], ufc[FBS];                  // t_q^kf ; column kf of L^^T
 #pragma unroll
-    for (int q = 0; q < NFQ; ++q) fbq[q] = FB[q * FBS + kf];
+    for (int q = 0; q < NFQ; ++q) fbq[q] = tab->face[C::FD].fb[q][kf];
 #pragma unroll
-    for (int j = 0; j < FBS; ++j) ufc[j] = LFT[j + kf * FBS];
+    for (int j = 0; j < FBS; ++j) ufc[j] = tab->face[C::FD].lft[j][kf];
 
     const size_t stride = (size_t)gridDim.x * C::CPW;
     for (size_t base = (size_t)blockIdx.x * C::CPW; base < a.n; base += stride) {
@@ -352,6 +412,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
         const size_t cell = a.first + (valid ? base + g : a.n - 1);
 
         // ================= S0: geometry (every lane of the group, registers) ==========
+        PA_MARK("S0");
         const uint4 idv = *reinterpret_cast<const uint4 *>(a.ptids + 4 * cell);
         const double2 q0 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.x);
         const double2 q1 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.y);
@@ -394,6 +455,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
         }
 
         // ================= S1: evaluation points ======================================
+        PA_MARK("S1");
 #pragma unroll
         for (int r = 0; r < C::PPL; ++r) {
             const int p = l + r * G;
@@ -465,7 +527,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                             if (m > 0) {
                                 const double gx = ex_ == 0 ? 0.0 : (ex_ * gnx) * pwx[ex_ > 0 ? ex_ - 1 : 0] * pwy[ey_];
                                 const double gy = ey_ == 0 ? 0.0 : (ey_ * gny) * pwx[ex_] * pwy[ey_ > 0 ? ey_ - 1 : 0];
-                                S[C::oDN + pf * NR + (m - 1)] = gx + gy;
+                                S[C::oDN + pf * NRP + (m - 1)] = gx + gy;
                             }
                         }
                     }
@@ -475,6 +537,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
         __syncthreads();
 
         // ================= S2: cell moments ===========================================
+        PA_MARK("S2");
 #pragma unroll
         for (int t = 0; t < C::MPL; ++t) {
             if (l + t * G < C::NMOM) {
@@ -487,6 +550,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
         __syncthreads();
 
         // ================= S3: stiffness (+mass) from moments ========================
+        PA_MARK("S3");
         {
             const double ih2 = ih * ih;
 #pragma unroll
@@ -496,7 +560,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                     const uint32_t code = st_code[t];
                     const double c1 = (double)((code >> 16) & 0xff), c2 = (double)(code >> 24);
                     const double v = c1 * S[C::oMOM + (code & 0xff)] + c2 * S[C::oMOM + ((code >> 8) & 0xff)];
-                    S[C::oST + e] = ih2 * v;
+                    S[C::oST + (e % RBS) + (e / RBS) * LD] = ih2 * v;
                 }
             }
             if (C::GENERAL_FANCY) {
@@ -504,32 +568,50 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                     int ai, bi, aj, bj;
                     mono_exps(e % RBS, ai, bi);
                     mono_exps(e / RBS, aj, bj);
-                    S[C::oMA + e] = S[C::oMOM + mono_index(ai + aj, bi + bj)];
+                    S[C::oMA + (e % RBS) + (e / RBS) * LD] = S[C::oMOM + mono_index(ai + aj, bi + bj)];
                 }
             }
         }
         __syncthreads();
 
         // ================= S3b: column c of gr_rhs  hho.hpp:64-85 =====================
+        PA_MARK("S3b");
         const int c = l < MS ? l : 0;
         double col[NR];
         if (l < CBS) {
+            // stiff[1:, c] (contiguous, aligned) minus sum_pf (w dphi.n)[pf][:] phi_c(x_pf)
+            const double *stc = S + C::oST + 1 + c * LD;
 #pragma unroll
-            for (int i = 0; i < NR; ++i) col[i] = S[C::oST + (i + 1) + c * RBS];
+            for (int i = 0; i + 1 < NR; i += 2) {
+                const double2 v = lds_pair(stc + i);
+                col[i] = v.x; col[i + 1] = v.y;
+            }
+            if (NR & 1) col[NR - 1] = stc[NR - 1];
 #pragma unroll
             for (int pf = 0; pf < NFP; ++pf) {
                 const double ph = S[C::oPHF + pf * RBS + c];
+                const double *dn = S + C::oDN + pf * NRP;
 #pragma unroll
-                for (int i = 0; i < NR; ++i) col[i] -= S[C::oDN + pf * NR + i] * ph;
+                for (int i = 0; i + 1 < NR; i += 2) {
+                    const double2 v = lds_pair(dn + i);
+                    col[i] = __builtin_fma(-v.x, ph, col[i]);
+                    col[i + 1] = __builtin_fma(-v.y, ph, col[i + 1]);
+                }
+                if (NR & 1) col[NR - 1] = __builtin_fma(-dn[NR - 1], ph, col[NR - 1]);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NR; ++i) col[i] = 0.0;
 #pragma unroll
             for (int q = 0; q < NFQ; ++q) {
-                const int ob = C::oDN + (fc * NFQ + q) * NR;
+                const double *dn = S + C::oDN + (fc * NFQ + q) * NRP;
 #pragma unroll
-                for (int i = 0; i < NR; ++i) col[i] += S[ob + i] * fbq[q];
+                for (int i = 0; i + 1 < NR; i += 2) {
+                    const double2 v = lds_pair(dn + i);
+                    col[i] = __builtin_fma(v.x, fbq[q], col[i]);
+                    col[i + 1] = __builtin_fma(v.y, fbq[q], col[i + 1]);
+                }
+                if (NR & 1) col[NR - 1] = __builtin_fma(dn[NR - 1], fbq[q], col[NR - 1]);
             }
         }
         // trace columns / (|F|/2):  tr[fk] = sum_q w_q t_q^k phi_c(x_fq)   hho.hpp:209-216 / 133-140.
@@ -547,7 +629,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                 for (int q = 0; q < NFQ; ++q) {
                     const double ph = S[C::oPHF + (f * NFQ + q) * RBS + m];
 #pragma unroll
-                    for (int k = 0; k < FBS; ++k) ucol[f * FBS + k] += CW[q * FBS + k] * ph;
+                    for (int k = 0; k < FBS; ++k) ucol[f * FBS + k] += ft.cw[q][k] * ph;
                 }
             if (C::GENERAL_FANCY && l < RBS) {
 #pragma unroll
@@ -557,18 +639,20 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
         __syncthreads();
 
         // ================= S4/S5: L L^T = gr_lhs (in place in ST[1:,1:]) ; Y = L^-1 gr_rhs  hho.hpp:63,92
-        double *LG = S + C::oST + 1 + RBS;
-        int bad = lds_cholesky<NR, RBS, G>(LG, l);
-        lds_forward<NR, RBS>(LG, col);
+        PA_MARK("S4");
+        double *LG = S + C::oST + 1 + LD;        // stiff[1:,1:], symmetric: row-major == column-major
+        int bad = lds_cholesky<NR, LD, G>(LG, l);
+        lds_forward<NR, LD>(LG, col);
         if (l < MS) {
 #pragma unroll
             for (int k = 0; k < NR; ++k) S[C::oZ + k + c * ZS] = col[k];
+            if (NRP != NR) S[C::oZ + NR + c * ZS] = 0.0;
         }
         double ycol[NR];
 #pragma unroll
         for (int k = 0; k < NR; ++k) ycol[k] = col[k];
         if (C::GENERAL_FANCY || a.oper != nullptr) {
-            lds_backward<NR, RBS>(LG, col);                 // col = oper[:, c]
+            lds_backward<NR, LD>(LG, col);                 // col = oper[:, c]
             if (a.oper != nullptr && valid && l < MS) {
                 double *dst = a.oper + (cell - a.first) * (size_t)(NR * MS) + (size_t)c * NR;
 #pragma unroll
@@ -577,6 +661,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
         }
 
         // ================= S6: column c of U ==========================================
+        PA_MARK("S6");
         if (C::HAS_STAB) {
             if (C::GENERAL_FANCY) {
                 // proj1[:, c] = e_c - M1^-1 (M2 R[:, c])   hho.hpp:184-190
@@ -585,14 +670,14 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                 for (int i = 0; i < CBS; ++i) {
                     double s = 0.0;
 #pragma unroll
-                    for (int k = 0; k < NR; ++k) s += S[C::oMA + i + (1 + k) * RBS] * col[k];
+                    for (int k = 0; k < NR; ++k) s += S[C::oMA + i + (1 + k) * LD] * col[k];
                     pr[i] = s;
                 }
                 __syncthreads();
-                const int badm = lds_cholesky<CBS, RBS, G>(S + C::oMA, l);
+                const int badm = lds_cholesky<CBS, LD, G>(S + C::oMA, l);
                 if (badm && !bad) bad = 100 + badm;
-                lds_forward<CBS, RBS>(S + C::oMA, pr);
-                lds_backward<CBS, RBS>(S + C::oMA, pr);
+                lds_forward<CBS, LD>(S + C::oMA, pr);
+                lds_backward<CBS, LD>(S + C::oMA, pr);
 #pragma unroll
                 for (int i = 0; i < CBS; ++i) pr[i] = (i == c ? 1.0 : 0.0) - pr[i];
                 // T_F[:, c] / (|F|/2) = MR1 R[:, c] + MR2 proj1[:, c]   (hho.hpp:222-230; piKF.solve is linear)
@@ -617,7 +702,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
                 double xf[FBS];
 #pragma unroll
                 for (int k = 0; k < FBS; ++k) xf[k] = ucol[f * FBS + k];
-                lds_forward<FBS, FBS>(LF, xf);
+                face_forward<FBS>(ft, xf);
 #pragma unroll
                 for (int k = 0; k < FBS; ++k) {
                     const double e = (l >= CBS && fc == f) ? ufc[k] : 0.0;      // (L^^T E_F)[k][c]
@@ -626,25 +711,21 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
             }
             if (l < MS) {
 #pragma unroll
-                for (int r = 0; r < NF; ++r) S[C::oZ + NR + r + c * ZS] = ucol[r];
+                for (int r = 0; r < NF; ++r) S[C::oZ + NRP + r + c * ZS] = ucol[r];
             }
         }
         __syncthreads();
 
         // ================= S7: lc = Z^T Z, entries (c, c + d mod MS) ==================
+        PA_MARK("S7");
         double acc_d[ND], acc_s[ND];
         {
             int cp = c;
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const double *zc = S + C::oZ + cp * ZS;
-                double s = 0.0, u = 0.0;
-#pragma unroll
-                for (int k = 0; k < NR; ++k) s += ycol[k] * zc[k];
-                if (C::HAS_STAB) {
-#pragma unroll
-                    for (int r = 0; r < NF; ++r) u += ucol[r] * zc[NR + r];
-                }
+                double s = lds_dotadd<NR>(0.0, zc, ycol), u = 0.0;
+                if (C::HAS_STAB) u = lds_dotadd<NF>(0.0, zc + NRP, ucol);
                 asm volatile("" : "+v"(s), "+v"(u));     // pin: keep the FMAs next to their LDS reads
                 acc_d[d] = s; acc_s[d] = u;
                 cp = (cp + 1 == MS) ? 0 : cp + 1;
@@ -653,6 +734,7 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
         __syncthreads();      // every read of L (region A) and Z is done: region A becomes the output image
 
         // ================= S8: mirror through LDS, stream to HBM ======================
+        PA_MARK("S8");
 #pragma unroll
         for (int which = 0; which < 3; ++which) {
             double *dst = which == 0 ? a.lc : which == 1 ? a.data : a.stab;

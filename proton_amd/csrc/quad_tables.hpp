@@ -52,6 +52,45 @@ inline void fill_gauss(QuadTables &t)
     }
 }
 
+// Face tables (hho_device.hpp FaceTables): for face degree fd the face basis at the n = fd + 1 Gauss
+// points is t_q^k (bases.hpp:269-272 on the segment), the face mass matrix is (|F|/2) M^ with
+// M^[i][j] = sum_q w_q t_q^(i+j) (hho.hpp:138,214); L^ is its Cholesky factor.
+inline void fill_face_tables(QuadTables &t)
+{
+    std::memset(t.face, 0, sizeof(t.face));
+    for (int fd = 0; fd < 4; ++fd) {
+        FaceTables &f = t.face[fd];
+        const int n = fd + 1, fbs = fd + 1;
+        for (int q = 0; q < n; ++q) {
+            double v = 1.0;
+            for (int k = 0; k < fbs; ++k) {
+                f.fb[q][k] = v;
+                f.cw[q][k] = t.gauss_w[n][q] * v;
+                v *= t.gauss_x[n][q];
+            }
+        }
+        double M[4][4] = {{0}}, L[4][4] = {{0}};
+        for (int i = 0; i < fbs; ++i)
+            for (int j = 0; j < fbs; ++j)
+                for (int q = 0; q < n; ++q) M[i][j] += f.cw[q][i] * f.fb[q][j];
+        for (int j = 0; j < fbs; ++j) {
+            double d = M[j][j];
+            for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+            L[j][j] = std::sqrt(d);
+            for (int i = j + 1; i < fbs; ++i) {
+                double s = M[i][j];
+                for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+                L[i][j] = s / L[j][j];
+            }
+        }
+        for (int i = 0; i < fbs; ++i)
+            for (int k = 0; k <= i; ++k) {
+                f.lf[i][k] = (i == k) ? 1.0 / L[i][i] : L[i][k];
+                f.lft[k][i] = L[i][k];
+            }
+    }
+}
+
 struct DunavantOrbit { int mult; double a, b, c, w; };   // mult 1: (a,a,a); 3: one a two b; 6: all distinct
 
 inline void fill_dunavant(QuadTables &t)
