@@ -231,3 +231,23 @@ def test_full_size_properties(asm, oracle, N, cd, fd):
         st, r = oracle.local_ops_batch(points, ptids, di, pa.QUAD_TENSOR, pa.STAB_FANCY, first=c, n=1, want=("lc",))
         got = lc[c].cpu().numpy().T
         assert nerr(got, r["lc"][0]) < TOL
+
+
+@pytest.mark.parametrize("N,degree", [(16, 0), (16, 1), (32, 1)])
+def test_obstacle_end_to_end_on_gpu_operators(asm, N, degree):
+    """configs[3] plumbing: the obstacle driver (apps/obstacle/obstacle.cpp:47-227) fed with the GPU's
+    local operators reproduces apps/obstacle/results/convergence.txt to its printed digits."""
+    import obstacle_driver as od
+    import proton_amd as pa
+    from proton_amd.batch import to_rowcol
+    REF = {16: (1.2833, 0.0588187), 32: (0.650286, 0.0171607)}
+
+    def gpu_provider(msh, deg):
+        asm.set_mesh(msh.points, msh.ptids)
+        out = asm.local_ops(0, deg, pa.QUAD_TENSOR, pa.STAB_FANCY, want=("lc",))
+        rhs = asm.cell_rhs(0, pa.capi.FN_OBSTACLE_RHS, pa.QUAD_TENSOR, dinc=1)
+        asm.synchronize()
+        return to_rowcol(out["lc"]), rhs.cpu().numpy()
+
+    err, iters = od.run_obstacle(N, degree, local_provider=gpu_provider)
+    assert abs(err - REF[N][degree]) / REF[N][degree] < 5e-6
