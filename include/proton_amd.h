@@ -144,6 +144,45 @@ int pa_static_condensation_batch(pa_context *ctx, pa_degree_info di, size_t n,
                                  const double *d_lc, const double *d_rhs,
                                  double *d_S, double *d_g, double *d_rec, int32_t *d_info);
 
+/* ---- assembler<Mesh> (hho.hpp:252-463) ---------------------------------------------------
+ * Face connectivity.  pa_mesh_generate builds it in closed form; for an uploaded mesh supply
+ * msh.faces as the reference holds them (basic_mesh.hpp:114-137, sorted by (lo,hi) point ids):
+ * cell_faces[c][4] = offset(msh, fc) of faces(msh, cl) (basic_geom.hpp:183-212, order bottom,
+ * right, top, left), face_pts[f][2] = fc.ptids (lo, hi), face_is_dirichlet[f] =
+ * fc.is_boundary && fc.bndtype == DIRICHLET.  Host arrays; copied. */
+int pa_mesh_set_faces(pa_context *ctx, const uint32_t *cell_faces, const uint32_t *face_pts,
+                      const uint8_t *face_is_dirichlet, size_t nfaces);
+
+typedef struct {
+    uint64_t system_size;        /* cbs * ncells + fbs * num_other_faces        hho.hpp:331      */
+    uint64_t ncells_global;      /* cells of the whole mesh                                       */
+    uint64_t cell_base;          /* global id of the context's cell 0 (row partition)             */
+    uint64_t nfaces_local;       /* rows of the context's face tables (d_g has nfaces_local x fbs) */
+    uint64_t face_base;          /* global id of local face 0                                      */
+    uint64_t num_other_faces;    /* non-Dirichlet faces of the whole mesh       hho.hpp:305-307   */
+} pa_assembler_info;
+int pa_assembler_query(pa_context *ctx, pa_degree_info di, pa_assembler_info *out);
+
+/* Dirichlet data of every boundary face, mass.llt().solve(rhs) of the boundary function
+ * (hho.hpp:381-386): d_g[f][fbs], zeros for non-Dirichlet faces.  fn = PA_FN_*; with
+ * PA_FN_SAMPLED d_fvals holds the function at the face quadrature points (nfaces_local x
+ * (face_deg+1), the points come from pa_face_quadrature_points). */
+int pa_dirichlet_data_batch(pa_context *ctx, int face_deg, int fn, const double *d_fvals, double *d_g);
+/* integrate(msh, fc, 2*face_deg) quadratures.hpp:404-432: d_xyw[f][face_deg+1][3] */
+int pa_face_quadrature_points(pa_context *ctx, int face_deg, double *d_xyw);
+
+/* assembler::assemble (hho.hpp:344-406) for cells [first, first+n): per cell msize^2 triplet
+ * slots in the reference's push order (slot i*msize + j for local row i, column j); a slot whose
+ * row or column belongs to a Dirichlet face holds row = col = -1.  Row/column indices are the
+ * reference's int triplet indices (Eigen::Triplet<T>).  The right-hand-side updates of
+ * hho.hpp:401,405 are returned per local row: d_rhs_rows[c][msize] (global row or -1) and
+ * d_rhs_vals[c][msize]; RHS = scatter-add of those.  d_lc: n x msize^2, d_rhs: n x cbs or NULL,
+ * d_g from pa_dirichlet_data_batch or NULL (homogeneous). */
+int pa_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n,
+                      const double *d_lc, const double *d_rhs, const double *d_g,
+                      int32_t *d_rows, int32_t *d_cols, double *d_vals,
+                      int32_t *d_rhs_rows, double *d_rhs_vals);
+
 /* occupancy / launch facts of the dominant kernel for the roofline bookkeeping */
 typedef struct {
     int32_t lanes_per_cell, cells_per_block, block_threads, lds_bytes_per_block;

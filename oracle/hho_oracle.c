@@ -866,6 +866,73 @@ int hho_mesh_face_is_boundary(const hho_mesh_params *p, size_t i, size_t j, int 
 }
 
 /* ------------------------------------------------------------------ */
+/* assembler<Mesh>  hho.hpp:252-463                                    */
+/* ------------------------------------------------------------------ */
+size_t hho_assembler_compress_table(const uint8_t *is_dirichlet, size_t nfaces, int64_t *compress)
+{
+    size_t co = 0;                                           /* hho.hpp:313-323 */
+    for (size_t i = 0; i < nfaces; i++) {
+        if (!is_dirichlet[i]) compress[i] = (int64_t)co++;
+        else compress[i] = -1;
+    }
+    return co;
+}
+
+size_t hho_assembler_system_size(hho_degrees di, size_t ncells, size_t num_other_faces)
+{
+    return (size_t)hho_cell_basis_size(di.cell_deg) * ncells + (size_t)hho_face_basis_size(di.face_deg) * num_other_faces;
+}
+
+int hho_dirichlet_face_data(const double p0[2], const double p1[2], int facdeg, hho_scalar_fn bf, void *user, double *out)
+{
+    double mass[HHO_MAX_FBS * HHO_MAX_FBS];
+    int fbs = hho_face_basis_size(facdeg);
+    int st = hho_face_mass_matrix(p0, p1, facdeg, 0, mass);   /* hho.hpp:383 */
+    if (st) return st;
+    st = hho_face_rhs(p0, p1, facdeg, 0, bf, user, out);      /* hho.hpp:384 */
+    if (st) return st;
+    int bad = hho_llt_factor(mass, fbs);
+    hho_llt_solve_inplace(mass, fbs, out, 1);                 /* hho.hpp:385 */
+    return bad ? HHO_ERR_NOT_SPD : HHO_OK;
+}
+
+int hho_assembler_assemble_cell(hho_degrees di, size_t cell_offset, size_t ncells,
+                                const uint64_t face_ids[4], const uint8_t face_dirichlet[4],
+                                const int64_t *compress, const double *lhs, const double *rhs,
+                                const double *dirichlet_data,
+                                int32_t *trip_rows, int32_t *trip_cols, double *trip_vals, size_t *ntrip,
+                                int64_t *rhs_rows, double *rhs_vals)
+{
+    int cbs = hho_cell_basis_size(di.cell_deg), fbs = hho_face_basis_size(di.face_deg);
+    int msize = cbs + 4 * fbs;
+    int64_t idx[HHO_MAX_MSIZE];
+    int assem[HHO_MAX_MSIZE];
+    size_t cell_LHS_offset = cell_offset * (size_t)cbs;               /* :362-363 */
+    for (int i = 0; i < cbs; i++) { idx[i] = (int64_t)(cell_LHS_offset + i); assem[i] = 1; }   /* :365-366 */
+    for (int f = 0; f < 4; f++) {                                      /* :370-387 */
+        int dirichlet = face_dirichlet[f];
+        int64_t face_LHS_offset = (int64_t)((size_t)cbs * ncells) + (dirichlet ? 0 : compress[face_ids[f]]) * fbs;   /* :374 */
+        for (int i = 0; i < fbs; i++) { idx[cbs + f * fbs + i] = face_LHS_offset + i; assem[cbs + f * fbs + i] = !dirichlet; }
+    }
+    size_t nt = 0;
+    for (int i = 0; i < msize; i++) {
+        rhs_rows[i] = assem[i] ? idx[i] : -1;
+        rhs_vals[i] = 0.0;
+    }
+    for (int i = 0; i < msize; i++) {                                  /* :391-403 */
+        if (!assem[i]) continue;
+        for (int j = 0; j < msize; j++) {
+            double v = lhs[IDX(i, j, msize)];
+            if (assem[j]) { trip_rows[nt] = (int32_t)idx[i]; trip_cols[nt] = (int32_t)idx[j]; trip_vals[nt] = v; nt++; }
+            else rhs_vals[i] -= v * dirichlet_data[j];
+        }
+    }
+    for (int i = 0; i < cbs; i++) rhs_vals[i] += rhs[i];              /* :405 */
+    *ntrip = nt;
+    return HHO_OK;
+}
+
+/* ------------------------------------------------------------------ */
 /* Batched loop == the reference's per-cell "Matrix assembly" span     */
 /* (convergence_test.cpp:202-213 without the triplet push).            */
 /* ------------------------------------------------------------------ */

@@ -92,6 +92,39 @@ class BatchAssembler:
                                      info.data_ptr())
         return S, g, rec, info
 
+    # ---- assembler (hho.hpp:252-463) -------------------------------------------------
+    def set_faces(self, cell_faces, face_pts, face_is_dirichlet):
+        self.ctx.mesh_set_faces(cell_faces, face_pts, face_is_dirichlet)
+
+    def assembler_info(self, cd, fd):
+        di, _ = capi.degree_info(cd, fd)
+        return self.ctx.assembler_query(di)
+
+    def dirichlet_data(self, fd, fn, fvals=None):
+        info = self.assembler_info(fd, fd)
+        g = torch.empty((info.nfaces_local, fd + 1), dtype=torch.float64, device=self.device)
+        self.ctx.dirichlet_data(fd, fn, g.data_ptr(), _ptr(fvals))
+        return g
+
+    def face_quadrature_points(self, fd):
+        info = self.assembler_info(fd, fd)
+        out = torch.empty((info.nfaces_local, fd + 1, 3), dtype=torch.float64, device=self.device)
+        self.ctx.face_quadrature_points(fd, out.data_ptr())
+        return out
+
+    def triplets(self, cd, fd, lc, rhs=None, g=None, first=0):
+        """assembler::assemble for the cells lc covers -> (rows, cols, vals, rhs_rows, rhs_vals)."""
+        di, _ = capi.degree_info(cd, fd)
+        n, ms = lc.shape[0], lc.shape[1]
+        rows = torch.empty((n, ms * ms), dtype=torch.int32, device=self.device)
+        cols = torch.empty((n, ms * ms), dtype=torch.int32, device=self.device)
+        vals = torch.empty((n, ms * ms), dtype=torch.float64, device=self.device)
+        rhs_rows = torch.empty((n, ms), dtype=torch.int32, device=self.device)
+        rhs_vals = torch.empty((n, ms), dtype=torch.float64, device=self.device)
+        self.ctx.triplets(di, first, n, lc.data_ptr(), _ptr(rhs), _ptr(g), rows.data_ptr(), cols.data_ptr(),
+                          vals.data_ptr(), rhs_rows.data_ptr(), rhs_vals.data_ptr())
+        return rows, cols, vals, rhs_rows, rhs_vals
+
     def synchronize(self):
         self.ctx.synchronize()
 

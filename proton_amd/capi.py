@@ -24,6 +24,8 @@ EXPORTS = [
     "pa_mesh_upload", "pa_mesh_attach_device", "pa_mesh_generate", "pa_mesh_counts",
     "pa_local_ops_batch", "pa_cell_rhs_batch", "pa_cell_quadrature_points",
     "pa_static_condensation_batch", "pa_local_ops_launch_info",
+    "pa_mesh_set_faces", "pa_assembler_query", "pa_dirichlet_data_batch", "pa_face_quadrature_points",
+    "pa_triplets_batch",
 ]
 
 
@@ -39,6 +41,11 @@ class Sizes(C.Structure):
 class LaunchInfo(C.Structure):
     _fields_ = [("lanes_per_cell", C.c_int32), ("cells_per_block", C.c_int32), ("block_threads", C.c_int32),
                 ("lds_bytes_per_block", C.c_int32), ("grid_blocks", C.c_int32), ("kernel_name", C.c_char_p)]
+
+
+class AssemblerInfo(C.Structure):
+    _fields_ = [("system_size", C.c_uint64), ("ncells_global", C.c_uint64), ("cell_base", C.c_uint64),
+                ("nfaces_local", C.c_uint64), ("face_base", C.c_uint64), ("num_other_faces", C.c_uint64)]
 
 
 class ProtonAmdError(RuntimeError):
@@ -92,6 +99,11 @@ def lib():
     L.pa_cell_quadrature_points.argtypes = [vp, C.c_int, C.c_int, sz, sz, dp, C.POINTER(C.c_int32)]
     L.pa_static_condensation_batch.argtypes = [vp, DegreeInfo, sz, dp, dp, dp, dp, dp, dp]
     L.pa_local_ops_launch_info.argtypes = [vp, DegreeInfo, C.c_int, C.c_int, sz, C.POINTER(LaunchInfo)]
+    L.pa_mesh_set_faces.argtypes = [vp, vp, vp, vp, sz]
+    L.pa_assembler_query.argtypes = [vp, DegreeInfo, C.POINTER(AssemblerInfo)]
+    L.pa_dirichlet_data_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
+    L.pa_face_quadrature_points.argtypes = [vp, C.c_int, dp]
+    L.pa_triplets_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp, dp, dp, dp, dp, dp]
     _lib = L
     return L
 
@@ -177,6 +189,29 @@ class Context:
     def static_condensation(self, di, n, lc, rhs=None, S=None, g=None, rec=None, info=None):
         self._ck(self._L.pa_static_condensation_batch(self.h, di, n, lc, rhs, S, g, rec, info),
                  "pa_static_condensation_batch")
+
+    def mesh_set_faces(self, cell_faces, face_pts, face_is_dirichlet):
+        import numpy as np
+        cf = np.ascontiguousarray(cell_faces, dtype=np.uint32)
+        fp = np.ascontiguousarray(face_pts, dtype=np.uint32)
+        fd = np.ascontiguousarray(face_is_dirichlet, dtype=np.uint8)
+        self._ck(self._L.pa_mesh_set_faces(self.h, cf.ctypes.data, fp.ctypes.data, fd.ctypes.data, fd.shape[0]),
+                 "pa_mesh_set_faces")
+
+    def assembler_query(self, di):
+        info = AssemblerInfo()
+        self._ck(self._L.pa_assembler_query(self.h, di, C.byref(info)), "pa_assembler_query")
+        return info
+
+    def dirichlet_data(self, face_deg, fn, g, fvals=None):
+        self._ck(self._L.pa_dirichlet_data_batch(self.h, face_deg, fn, fvals, g), "pa_dirichlet_data_batch")
+
+    def face_quadrature_points(self, face_deg, xyw):
+        self._ck(self._L.pa_face_quadrature_points(self.h, face_deg, xyw), "pa_face_quadrature_points")
+
+    def triplets(self, di, first, n, lc, rhs, g, rows, cols, vals, rhs_rows, rhs_vals):
+        self._ck(self._L.pa_triplets_batch(self.h, di, first, n, lc, rhs, g, rows, cols, vals, rhs_rows, rhs_vals),
+                 "pa_triplets_batch")
 
     def launch_info(self, di, quad, stab, n):
         li = LaunchInfo()

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "../../include/proton_amd.h"
+#include "hho_assembly.hpp"
 #include "hho_aux.hpp"
 #include "hho_launch.hpp"
 #include "quad_tables.hpp"
@@ -61,6 +62,11 @@ struct pa_context {
     uint32_t *d_ptids = nullptr;
     size_t npoints = 0, ncells = 0;
     bool owns_mesh = false;
+    // face connectivity for the assembler
+    uint32_t *d_cell_faces = nullptr, *d_face_pts = nullptr;
+    uint8_t *d_face_dir = nullptr;
+    int32_t *d_face_compress = nullptr;
+    size_t nfaces_local = 0, face_base = 0, num_other_faces = 0, ncells_global = 0, cell_base = 0;
     std::string last_error;
 };
 
@@ -73,8 +79,19 @@ struct pa_context {
         }                                                                                         \
     } while (0)
 
+static void release_faces(pa_context *ctx)
+{
+    if (ctx->d_cell_faces) (void)hipFree(ctx->d_cell_faces);
+    if (ctx->d_face_pts) (void)hipFree(ctx->d_face_pts);
+    if (ctx->d_face_dir) (void)hipFree(ctx->d_face_dir);
+    if (ctx->d_face_compress) (void)hipFree(ctx->d_face_compress);
+    ctx->d_cell_faces = ctx->d_face_pts = nullptr; ctx->d_face_dir = nullptr; ctx->d_face_compress = nullptr;
+    ctx->nfaces_local = ctx->face_base = ctx->num_other_faces = 0;
+}
+
 static void release_mesh(pa_context *ctx)
 {
+    release_faces(ctx);
     if (ctx->owns_mesh) {
         if (ctx->d_points) (void)hipFree(ctx->d_points);
         if (ctx->d_ptids) (void)hipFree(ctx->d_ptids);
@@ -234,6 +251,7 @@ int pa_mesh_upload(pa_context *ctx, const double *points, size_t npoints, const 
     PA_HIP(ctx, hipMemcpyAsync(ctx->d_ptids, cell_ptids, ncells * 4 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->npoints = npoints; ctx->ncells = ncells;
+    ctx->ncells_global = ncells; ctx->cell_base = 0;
     return PA_OK;
 }
 
@@ -244,6 +262,7 @@ int pa_mesh_attach_device(pa_context *ctx, const double *d_points, size_t npoint
     ctx->d_points = const_cast<double *>(d_points);
     ctx->d_ptids = const_cast<uint32_t *>(d_cell_ptids);
     ctx->npoints = npoints; ctx->ncells = ncells; ctx->owns_mesh = false;
+    ctx->ncells_global = ncells; ctx->cell_base = 0;
     return PA_OK;
 }
 
@@ -266,6 +285,116 @@ int pa_mesh_generate(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double
                        Nx, row_begin, row_end, min_x, hx, min_y, hy);
     PA_HIP(ctx, hipGetLastError());
     ctx->npoints = np; ctx->ncells = nc;
+    ctx->ncells_global = Nx * Ny; ctx->cell_base = row_begin * Nx;
+    // face connectivity in closed form (basic_mesh.hpp:266-297)
+    pa::StructuredMesh sm = {(uint32_t)Nx, (uint32_t)Ny, (uint32_t)row_begin, (uint32_t)row_end};
+    const uint32_t nfl = pa::sm_faces_local(sm);
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_cell_faces, nc * 4 * sizeof(uint32_t)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_face_pts, (size_t)nfl * 2 * sizeof(uint32_t)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_face_dir, nfl));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_face_compress, (size_t)nfl * sizeof(int32_t)));
+    const uint32_t nthreads = nfl > nc ? nfl : (uint32_t)nc;
+    hipLaunchKernelGGL(pa::structured_faces_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, ctx->stream, sm, nfl,
+                       ctx->d_face_pts, ctx->d_face_dir, ctx->d_face_compress, (uint32_t)nc, ctx->d_cell_faces);
+    PA_HIP(ctx, hipGetLastError());
+    ctx->nfaces_local = nfl; ctx->face_base = pa::sm_face_base(sm); ctx->num_other_faces = pa::sm_num_other_faces(sm);
+    return PA_OK;
+}
+
+int pa_mesh_set_faces(pa_context *ctx, const uint32_t *cell_faces, const uint32_t *face_pts,
+                      const uint8_t *face_is_dirichlet, size_t nfaces)
+{
+    if (!ctx || !cell_faces || !face_pts || !face_is_dirichlet || nfaces == 0) return PA_ERR_INVALID_ARG;
+    if (!ctx->d_points) return PA_ERR_NO_MESH;
+    for (size_t i = 0; i < 4 * ctx->ncells; ++i)
+        if (cell_faces[i] >= nfaces) return PA_ERR_INVALID_ARG;
+    for (size_t i = 0; i < 2 * nfaces; ++i)
+        if (face_pts[i] >= ctx->npoints) return PA_ERR_INVALID_ARG;
+    PA_HIP(ctx, hipSetDevice(ctx->device));
+    release_faces(ctx);
+    // compress table, hho.hpp:313-323
+    int32_t *comp = (int32_t *)std::malloc(nfaces * sizeof(int32_t));
+    if (!comp) return PA_ERR_INVALID_ARG;
+    size_t co = 0;
+    for (size_t i = 0; i < nfaces; ++i) comp[i] = face_is_dirichlet[i] ? -1 : (int32_t)co++;
+    hipError_t e = hipMalloc((void **)&ctx->d_cell_faces, (ctx->ncells ? ctx->ncells : 1) * 4 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_face_pts, nfaces * 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_face_dir, nfaces);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_face_compress, nfaces * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_cell_faces, cell_faces, ctx->ncells * 4 * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_face_pts, face_pts, nfaces * 2 * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_face_dir, face_is_dirichlet, nfaces, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_face_compress, comp, nfaces * sizeof(int32_t), hipMemcpyHostToDevice);
+    std::free(comp);
+    if (e != hipSuccess) { ctx->last_error = std::string("pa_mesh_set_faces: ") + hipGetErrorString(e); return PA_ERR_HIP; }
+    ctx->nfaces_local = nfaces; ctx->face_base = 0; ctx->num_other_faces = co;
+    return PA_OK;
+}
+
+int pa_assembler_query(pa_context *ctx, pa_degree_info di, pa_assembler_info *out)
+{
+    if (!ctx || !out || di.cell_deg < 0 || di.face_deg < 0) return PA_ERR_INVALID_ARG;
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    out->ncells_global = ctx->ncells_global; out->cell_base = ctx->cell_base;
+    out->nfaces_local = ctx->nfaces_local; out->face_base = ctx->face_base;
+    out->num_other_faces = ctx->num_other_faces;
+    out->system_size = (uint64_t)pa::P2(di.cell_deg) * ctx->ncells_global + (uint64_t)(di.face_deg + 1) * ctx->num_other_faces;
+    return PA_OK;
+}
+
+int pa_dirichlet_data_batch(pa_context *ctx, int face_deg, int fn, const double *d_fvals, double *d_g)
+{
+    if (!ctx || !d_g || face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_ARG;
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    if (fn < PA_FN_SAMPLED || fn > PA_FN_ONE || (fn == PA_FN_SAMPLED && !d_fvals)) return PA_ERR_INVALID_ARG;
+    const uint32_t nf = (uint32_t)ctx->nfaces_local;
+    const dim3 grid((nf + 255) / 256), block(256);
+#define PA_DD_CASE(FD)                                                                                              \
+    case FD:                                                                                                        \
+        hipLaunchKernelGGL((pa::dirichlet_data_kernel<FD>), grid, block, 0, ctx->stream, ctx->d_tab, ctx->d_points, \
+                           ctx->d_face_pts, ctx->d_face_dir, nf, fn, d_fvals, d_g);                                 \
+        break;
+    switch (face_deg) { PA_DD_CASE(0) PA_DD_CASE(1) PA_DD_CASE(2) PA_DD_CASE(3) }
+#undef PA_DD_CASE
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
+int pa_face_quadrature_points(pa_context *ctx, int face_deg, double *d_xyw)
+{
+    if (!ctx || !d_xyw || face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_ARG;
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    const uint32_t nf = (uint32_t)ctx->nfaces_local;
+    hipLaunchKernelGGL(pa::face_qpoints_kernel, dim3((nf + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_tab,
+                       ctx->d_points, ctx->d_face_pts, nf, face_deg + 1, d_xyw);
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
+int pa_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n, const double *d_lc,
+                      const double *d_rhs, const double *d_g, int32_t *d_rows, int32_t *d_cols, double *d_vals,
+                      int32_t *d_rhs_rows, double *d_rhs_vals)
+{
+    if (!ctx || !d_lc || !d_rows || !d_cols || !d_vals || !d_rhs_rows || !d_rhs_vals) return PA_ERR_INVALID_ARG;
+    if (di.cell_deg < 0 || di.face_deg < 0 || di.face_deg > 3 || di.cell_deg > 4) return PA_ERR_INVALID_DEGREE;
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
+    pa_assembler_info info;
+    pa_assembler_query(ctx, di, &info);
+    if (info.system_size >= ((uint64_t)1 << 31)) return PA_ERR_INVALID_ARG;      // Eigen::Triplet stores int indices
+    if (n == 0) return PA_OK;
+    pa::TripletArgs a;
+    a.cell_faces = ctx->d_cell_faces; a.face_dir = ctx->d_face_dir; a.face_compress = ctx->d_face_compress;
+    a.g = d_g; a.lc = d_lc; a.rhs = d_rhs; a.first = first; a.n = n;
+    a.cell_base = ctx->cell_base; a.ncells_global = ctx->ncells_global;
+    a.cbs = pa::P2(di.cell_deg); a.fbs = di.face_deg + 1;
+    a.rows = d_rows; a.cols = d_cols; a.vals = d_vals; a.rhs_rows = d_rhs_rows; a.rhs_vals = d_rhs_vals;
+    const int msize = a.cbs + 4 * a.fbs;
+    const size_t shmem = msize * sizeof(double) + msize * sizeof(int32_t);
+    const size_t resident = (size_t)ctx->num_cus * 8;
+    const int grid = (int)(n < resident ? n : resident);
+    hipLaunchKernelGGL(pa::triplets_kernel, dim3(grid), dim3(256), shmem, ctx->stream, a);
+    PA_HIP(ctx, hipGetLastError());
     return PA_OK;
 }
 

@@ -112,6 +112,14 @@ def lib():
     L.hho_mesh_face_is_boundary.argtypes = [mpp, C.c_size_t, C.c_size_t, C.c_int]
     L.hho_local_ops_batch.argtypes = [dp, u64p, C.c_size_t, C.c_size_t, Degrees, C.c_int, C.c_int,
                                       SCALAR_FN, C.c_void_p, C.c_int, dp, dp, dp, dp, dp]
+    i64p, i32p, u8p = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    L.hho_assembler_compress_table.restype = C.c_size_t
+    L.hho_assembler_compress_table.argtypes = [u8p, C.c_size_t, i64p]
+    L.hho_assembler_system_size.restype = C.c_size_t
+    L.hho_assembler_system_size.argtypes = [Degrees, C.c_size_t, C.c_size_t]
+    L.hho_dirichlet_face_data.argtypes = [dp, dp, C.c_int, SCALAR_FN, C.c_void_p, dp]
+    L.hho_assembler_assemble_cell.argtypes = [Degrees, C.c_size_t, C.c_size_t, u64p, u8p, i64p, dp, dp, dp,
+                                              i32p, i32p, dp, C.POINTER(C.c_size_t), i64p, dp]
     L.hho_builtin_fn.restype = SCALAR_FN
     L.hho_builtin_fn.argtypes = [C.c_int]
     _LIB = L
@@ -247,3 +255,56 @@ def local_ops_batch(points, ptids, di, quad, stab, first=0, n=None, fn=None, rhs
     if rhs is not None:
         out["rhs"] = rhs
     return st, out
+
+
+class Assembler:
+    """assembler<Mesh> (hho.hpp:252-463) on the generator mesh, through the oracle's C restatement."""
+
+    def __init__(self, mp, points, ptids, di, bf_id=None):
+        L = lib()
+        self.mp, self.points, self.ptids, self.di = mp, points, ptids, di
+        self.faces, self.bnd = mesh_faces(mp)
+        self.nf, self.nc = self.faces.shape[0], ptids.shape[0]
+        self.is_dir = np.ascontiguousarray(self.bnd.astype(np.uint8))        # all boundary faces are Dirichlet
+        self.compress = np.zeros(self.nf, dtype=np.int64)
+        self.num_other = L.hho_assembler_compress_table(self.is_dir.ctypes.data_as(C.POINTER(C.c_uint8)), self.nf,
+                                                        self.compress.ctypes.data_as(C.POINTER(C.c_int64)))
+        self.system_size = L.hho_assembler_system_size(di, self.nc, self.num_other)
+        Nx = mp.Nx
+        self.cell_faces = np.zeros((self.nc, 4), dtype=np.uint64)
+        for c in range(self.nc):
+            for lf in range(4):
+                self.cell_faces[c, lf] = L.hho_mesh_face_id(C.byref(mp), c % Nx, c // Nx, lf)
+        self.g = np.zeros((self.nf, di.fbs))
+        if bf_id is not None:
+            fn = L.hho_builtin_fn(bf_id)
+            for f in np.nonzero(self.is_dir)[0]:
+                p0 = np.ascontiguousarray(points[int(self.faces[f, 0])])
+                p1 = np.ascontiguousarray(points[int(self.faces[f, 1])])
+                assert L.hho_dirichlet_face_data(_dp(p0), _dp(p1), di.face_deg, fn, None, _dp(self.g[f])) == 0
+
+    def assemble_cell(self, c, lhs_rowcol, rhs):
+        """-> (rows, cols, vals) in push order, rhs_rows[msize], rhs_vals[msize]"""
+        L = lib()
+        di = self.di
+        ms, cbs, fbs = di.msize, di.cbs, di.fbs
+        lhs = np.ascontiguousarray(lhs_rowcol.T)
+        rhs = np.ascontiguousarray(np.asarray(rhs, dtype=np.float64))
+        fids = np.ascontiguousarray(self.cell_faces[c])
+        fdir = np.ascontiguousarray(self.is_dir[fids.astype(np.int64)])
+        dd = np.zeros(ms)
+        for lf in range(4):
+            dd[cbs + lf * fbs: cbs + (lf + 1) * fbs] = self.g[int(fids[lf])]
+        tr = np.zeros(ms * ms, dtype=np.int32)
+        tc = np.zeros(ms * ms, dtype=np.int32)
+        tv = np.zeros(ms * ms)
+        nt = C.c_size_t(0)
+        rr = np.zeros(ms, dtype=np.int64)
+        rv = np.zeros(ms)
+        st = L.hho_assembler_assemble_cell(di, c, self.nc, _u64p(fids), fdir.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                           self.compress.ctypes.data_as(C.POINTER(C.c_int64)), _dp(lhs), _dp(rhs), _dp(dd),
+                                           tr.ctypes.data_as(C.POINTER(C.c_int32)), tc.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           _dp(tv), C.byref(nt), rr.ctypes.data_as(C.POINTER(C.c_int64)), _dp(rv))
+        assert st == 0
+        n = nt.value
+        return tr[:n], tc[:n], tv[:n], rr, rv

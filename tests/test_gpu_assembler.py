@@ -1,0 +1,121 @@
+"""GPU assembler stage (assembler<Mesh>, hho.hpp:252-463) through the C ABI against the oracle's
+restatement: triplet (row, col) sequences and right-hand-side row maps BIT-EXACT, values exact copies
+of the local matrices, Dirichlet data and right-hand-side updates to rounding."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def asm():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    from proton_amd.batch import BatchAssembler
+    return BatchAssembler(0)
+
+
+def gpu_assembly(asm, N, cd, fd, rows=None):
+    import proton_amd as pa
+    asm.generate_mesh(N, N, rows=rows)
+    out = asm.local_ops(cd, fd, pa.QUAD_TENSOR, pa.STAB_FANCY, want=("lc",))
+    rhs = asm.cell_rhs(cd, pa.capi.FN_SIN_SIN_RHS, pa.QUAD_TENSOR)
+    g = asm.dirichlet_data(fd, pa.capi.FN_SIN_SIN_SOL)
+    r, c, v, rr, rv = asm.triplets(cd, fd, out["lc"], rhs, g)
+    asm.synchronize()
+    return out["lc"], rhs, g, r, c, v, rr, rv
+
+
+@pytest.mark.parametrize("N,cd,fd", [(5, 2, 1), (6, 3, 2), (4, 4, 3), (7, 0, 1), (5, 1, 1)])
+def test_triplets_bit_exact_index_maps(asm, oracle, N, cd, fd):
+    from proton_amd.batch import to_rowcol
+    lc, rhs, g, r, c, v, rr, rv = gpu_assembly(asm, N, cd, fd)
+    info = asm.assembler_info(cd, fd)
+    mp, points, ptids = oracle.make_mesh(N, N)
+    di = oracle.degrees(cd, fd)
+    ref = oracle.Assembler(mp, points, ptids, di, bf_id=2)
+    assert info.system_size == ref.system_size and info.num_other_faces == ref.num_other
+    assert info.ncells_global == N * N and info.cell_base == 0 and info.face_base == 0
+    # Dirichlet data (hho.hpp:381-386) on every face of the generator mesh
+    gh = g.cpu().numpy()
+    assert gh.shape[0] >= ref.nf
+    assert np.abs(gh[:ref.nf] - ref.g).max() < 1e-13 * max(1.0, np.abs(ref.g).max())
+    lch = to_rowcol(lc)
+    rhsh = rhs.cpu().numpy()
+    R, Cc, V, RR, RV = r.cpu().numpy(), c.cpu().numpy(), v.cpu().numpy(), rr.cpu().numpy(), rv.cpu().numpy()
+    ms = di.msize
+    for cell in range(N * N):
+        tr, tc, tv, rrow, rval = ref.assemble_cell(cell, lch[cell], rhsh[cell])
+        keep = R[cell] >= 0
+        assert np.array_equal(keep, Cc[cell] >= 0)
+        assert np.array_equal(R[cell][keep], tr)                      # bit-exact, in the reference's push order
+        assert np.array_equal(Cc[cell][keep], tc)
+        assert np.array_equal(V[cell][keep], tv)                      # exact copies of lhs(i,j)
+        assert np.array_equal(RR[cell].astype(np.int64), rrow)
+        assert np.abs(RV[cell] - rval).max() <= 1e-13 * max(1.0, np.abs(rval).max())
+        # slot layout: i*msize + j
+        assert np.array_equal(V[cell].reshape(ms, ms), lch[cell])
+
+
+def test_partition_and_uploaded_mesh_agree_with_generated(asm, oracle):
+    """cell rows [r0, r1) of the slab carry global indices; an uploaded mesh with explicit face tables
+    (pa_mesh_set_faces) gives the same triplets as the closed-form generator tables."""
+    import proton_amd as pa
+    N, cd, fd = 6, 2, 1
+    full = gpu_assembly(asm, N, cd, fd)
+    R, Cc, RR = full[3].cpu().numpy(), full[4].cpu().numpy(), full[6].cpu().numpy()
+    part = gpu_assembly(asm, N, cd, fd, rows=(2, 5))
+    info = asm.assembler_info(cd, fd)
+    assert info.cell_base == 2 * N and info.ncells_global == N * N
+    assert np.array_equal(part[3].cpu().numpy(), R[2 * N:5 * N])
+    assert np.array_equal(part[4].cpu().numpy(), Cc[2 * N:5 * N])
+    assert np.array_equal(part[6].cpu().numpy(), RR[2 * N:5 * N])
+    assert np.abs(part[7].cpu().numpy() - full[7].cpu().numpy()[2 * N:5 * N]).max() < 1e-13
+    # uploaded mesh + explicit tables
+    mp, points, ptids = oracle.make_mesh(N, N)
+    di = oracle.degrees(cd, fd)
+    ref = oracle.Assembler(mp, points, ptids, di)
+    asm.set_mesh(points, ptids)
+    asm.set_faces(ref.cell_faces, ref.faces, ref.is_dir)
+    out = asm.local_ops(cd, fd, pa.QUAD_TENSOR, pa.STAB_FANCY, want=("lc",))
+    rhs = asm.cell_rhs(cd, pa.capi.FN_SIN_SIN_RHS, pa.QUAD_TENSOR)
+    g = asm.dirichlet_data(fd, pa.capi.FN_SIN_SIN_SOL)
+    r, c, v, rr, rv = asm.triplets(cd, fd, out["lc"], rhs, g)
+    assert np.array_equal(r.cpu().numpy(), R) and np.array_equal(c.cpu().numpy(), Cc)
+    assert np.array_equal(rr.cpu().numpy(), RR)
+    # caller-sampled boundary function == built-in
+    import torch
+    xyw = asm.face_quadrature_points(fd)
+    fv = torch.sin(math.pi * xyw[:, :, 0]) * torch.sin(math.pi * xyw[:, :, 1])
+    g2 = asm.dirichlet_data(fd, pa.capi.FN_SAMPLED, fvals=fv.contiguous())
+    assert float((g2 - g).abs().max()) < 1e-13
+
+
+@pytest.mark.parametrize("cd,fd", [(2, 1), (3, 2)])
+def test_config1_plumbing_poisson_solve(asm, oracle, cd, fd):
+    """configs[0]: 32x32 k=1 Laplacian, GPU local operators + GPU triplets, host sparse solve:
+    same solution as the all-oracle path and the expected L2 order."""
+    import scipy.sparse as sp
+    import poisson_driver as pd
+    errs = []
+    for N in (16, 32):
+        lc, rhs, g, r, c, v, rr, rv = gpu_assembly(asm, N, cd, fd)
+        info = asm.assembler_info(cd, fd)
+        R, Cc, V = r.cpu().numpy().ravel(), c.cpu().numpy().ravel(), v.cpu().numpy().ravel()
+        keep = R >= 0
+        LHS = sp.csr_matrix((V[keep], (R[keep], Cc[keep])), shape=(info.system_size, info.system_size))
+        RHS = np.zeros(info.system_size)
+        RR, RV = rr.cpu().numpy().ravel(), rv.cpu().numpy().ravel()
+        ok = RR >= 0
+        np.add.at(RHS, RR[ok], RV[ok])
+        sol = pd.solve(LHS, RHS)
+        LHS_o, RHS_o, ref, di = pd.oracle_assembly(N, cd, fd)
+        assert abs(LHS - LHS_o).max() < 1e-11 * abs(LHS_o).max()
+        assert np.abs(RHS - RHS_o).max() < 1e-12 * max(1.0, np.abs(RHS_o).max())
+        sol_o = pd.solve(LHS_o, RHS_o)
+        assert np.abs(sol - sol_o).max() < 1e-9
+        errs.append(pd.l2_error(ref, di, sol))
+    assert math.log2(errs[0] / errs[1]) > fd + 2 - 0.3
