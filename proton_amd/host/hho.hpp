@@ -1,0 +1,789 @@
+// proton_amd/host/hho.hpp -- C++ host side of the MI355X-native HHO assembly path.
+//
+// Mirrors the reference's interface for this path (names, argument order, meaning), so a driver
+// written like apps/convergence_test or apps/obstacle compiles against it:
+//   mesh_init_params / quad_mesh            src/core/core_bits/basic_mesh.hpp:178-197, 210-299
+//   offset / faces / barycenter / diameter  src/core/core_bits/basic_geom.hpp:30-61, 183-212, 247-315
+//   hho_degree_info                         src/core/core_bits/utils.hpp:62-111
+//   make_rhs                                src/core/core_bits/utils.hpp:153-174
+//   make_hho_laplacian                      src/methods/hho_bits/hho.hpp:32-96
+//   make_hho_naive_stabilization            src/methods/hho_bits/hho.hpp:99-148
+//   make_hho_fancy_stabilization            src/methods/hho_bits/hho.hpp:155-237
+//   assembler / make_assembler              src/methods/hho_bits/hho.hpp:252-463
+// Everything numerical is computed on the GPU through the C ABI of include/proton_amd.h
+// (libproton_amd.so); there is no CPU fallback -- a missing library or GPU throws.
+//
+// The per-cell calls of the reference are served from a batch: the first call for a given
+// (mesh, degrees, quadrature, stabilization) computes ALL cells in one launch and caches the
+// result; later calls copy one cell out of it.  Large meshes should use the batched entry
+// points (proton_amd::local_operators / assemble_all) and keep the data on the device.
+//
+// Matrices are returned as proton_amd::dense_matrix<T>: column-major like Eigen's default,
+// with rows(), cols(), operator()(i,j), data(); if <Eigen/Dense> is available, map() gives an
+// Eigen::Map over the same storage.
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "../../include/proton_amd.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Dense>)
+#include <Eigen/Dense>
+#define PROTON_AMD_HAS_EIGEN 1
+#endif
+#endif
+
+namespace proton_amd {
+
+struct error : std::runtime_error {
+    int status;
+    error(int st, const std::string &what) : std::runtime_error(what), status(st) {}
+};
+
+inline const char *status_name(int st)
+{
+    switch (st) {
+    case PA_OK: return "PA_OK";
+    case PA_ERR_INVALID_ARG: return "PA_ERR_INVALID_ARG";
+    case PA_ERR_INVALID_DEGREE: return "PA_ERR_INVALID_DEGREE";
+    case PA_ERR_QUADRATURE: return "PA_ERR_QUADRATURE (Quadrature order too high)";
+    case PA_ERR_HIP: return "PA_ERR_HIP";
+    case PA_ERR_NO_MESH: return "PA_ERR_NO_MESH";
+    case PA_ERR_NOT_SPD: return "PA_ERR_NOT_SPD";
+    default: return "unknown status";
+    }
+}
+
+// one context per process (device 0 unless PROTON_AMD_DEVICE is set), library-owned stream
+class device {
+    pa_context *ctx_ = nullptr;
+
+  public:
+    device()
+    {
+        int dev = 0;
+        if (const char *e = std::getenv("PROTON_AMD_DEVICE")) dev = std::atoi(e);
+        const int st = pa_context_create(dev, nullptr, 1, &ctx_);
+        if (st != PA_OK) throw error(st, std::string("pa_context_create: ") + status_name(st) + " (no GPU? there is no CPU fallback)");
+    }
+    ~device() { if (ctx_) pa_context_destroy(ctx_); }
+    device(const device &) = delete;
+    device &operator=(const device &) = delete;
+    pa_context *ctx() const { return ctx_; }
+    void check(int st, const char *where) const
+    {
+        if (st != PA_OK) throw error(st, std::string(where) + ": " + status_name(st) + " " + pa_last_error(ctx_));
+    }
+    static device &instance()
+    {
+        static device d;
+        return d;
+    }
+};
+
+// RAII device buffer
+template <typename T>
+class device_buffer {
+    T *p_ = nullptr;
+    size_t n_ = 0;
+
+  public:
+    device_buffer() = default;
+    explicit device_buffer(size_t n) { resize(n); }
+    ~device_buffer() { release(); }
+    device_buffer(const device_buffer &) = delete;
+    device_buffer &operator=(const device_buffer &) = delete;
+    device_buffer(device_buffer &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    void release()
+    {
+        if (p_) pa_free(device::instance().ctx(), p_);
+        p_ = nullptr; n_ = 0;
+    }
+    void resize(size_t n)
+    {
+        release();
+        void *q = nullptr;
+        device::instance().check(pa_malloc(device::instance().ctx(), n * sizeof(T), &q), "pa_malloc");
+        p_ = static_cast<T *>(q); n_ = n;
+    }
+    T *get() const { return p_; }
+    size_t size() const { return n_; }
+    void upload(const T *src, size_t n) { device::instance().check(pa_memcpy_h2d(device::instance().ctx(), p_, src, n * sizeof(T)), "pa_memcpy_h2d"); }
+    void download(T *dst, size_t n, size_t offset = 0) const
+    {
+        device::instance().check(pa_memcpy_d2h(device::instance().ctx(), dst, p_ + offset, n * sizeof(T)), "pa_memcpy_d2h");
+    }
+};
+
+// column-major dense matrix (vectors are n x 1)
+template <typename T>
+class dense_matrix {
+    size_t r_ = 0, c_ = 0;
+    std::vector<T> v_;
+
+  public:
+    dense_matrix() = default;
+    dense_matrix(size_t r, size_t c, T init = T(0)) : r_(r), c_(c), v_(r * c, init) {}
+    static dense_matrix Zero(size_t r, size_t c = 1) { return dense_matrix(r, c); }
+    size_t rows() const { return r_; }
+    size_t cols() const { return c_; }
+    size_t size() const { return v_.size(); }
+    T *data() { return v_.data(); }
+    const T *data() const { return v_.data(); }
+    T &operator()(size_t i, size_t j) { return v_[i + j * r_]; }
+    const T &operator()(size_t i, size_t j) const { return v_[i + j * r_]; }
+    T &operator()(size_t i) { return v_[i]; }
+    const T &operator()(size_t i) const { return v_[i]; }
+    dense_matrix operator+(const dense_matrix &o) const
+    {
+        assert(r_ == o.r_ && c_ == o.c_);
+        dense_matrix m(r_, c_);
+        for (size_t i = 0; i < v_.size(); ++i) m.v_[i] = v_[i] + o.v_[i];
+        return m;
+    }
+    dense_matrix operator-(const dense_matrix &o) const
+    {
+        assert(r_ == o.r_ && c_ == o.c_);
+        dense_matrix m(r_, c_);
+        for (size_t i = 0; i < v_.size(); ++i) m.v_[i] = v_[i] - o.v_[i];
+        return m;
+    }
+    dense_matrix operator*(const dense_matrix &o) const
+    {
+        assert(c_ == o.r_);
+        dense_matrix m(r_, o.c_);
+        for (size_t j = 0; j < o.c_; ++j)
+            for (size_t k = 0; k < c_; ++k) {
+                const T b = o(k, j);
+                for (size_t i = 0; i < r_; ++i) m(i, j) += (*this)(i, k) * b;
+            }
+        return m;
+    }
+    dense_matrix operator*(T s) const
+    {
+        dense_matrix m(*this);
+        for (auto &x : m.v_) x *= s;
+        return m;
+    }
+    dense_matrix transpose() const
+    {
+        dense_matrix m(c_, r_);
+        for (size_t j = 0; j < c_; ++j)
+            for (size_t i = 0; i < r_; ++i) m(j, i) = (*this)(i, j);
+        return m;
+    }
+    dense_matrix block(size_t i0, size_t j0, size_t nr, size_t nc) const
+    {
+        dense_matrix m(nr, nc);
+        for (size_t j = 0; j < nc; ++j)
+            for (size_t i = 0; i < nr; ++i) m(i, j) = (*this)(i0 + i, j0 + j);
+        return m;
+    }
+    T dot(const dense_matrix &o) const
+    {
+        assert(v_.size() == o.v_.size());
+        T s = 0;
+        for (size_t i = 0; i < v_.size(); ++i) s += v_[i] * o.v_[i];
+        return s;
+    }
+#ifdef PROTON_AMD_HAS_EIGEN
+    Eigen::Map<Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic>> map() { return {v_.data(), (Eigen::Index)r_, (Eigen::Index)c_}; }
+#endif
+};
+
+// CSR matrix produced by assembler::finalize (setFromTriplets semantics: duplicates are summed)
+template <typename T>
+struct sparse_matrix {
+    size_t nrows = 0, ncols = 0;
+    std::vector<int64_t> rowptr;
+    std::vector<int32_t> colind;
+    std::vector<T> values;
+    size_t rows() const { return nrows; }
+    size_t cols() const { return ncols; }
+    size_t nonZeros() const { return values.size(); }
+    std::vector<T> multiply(const std::vector<T> &x) const
+    {
+        std::vector<T> y(nrows, T(0));
+        for (size_t i = 0; i < nrows; ++i) {
+            T s = 0;
+            for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) s += values[k] * x[colind[k]];
+            y[i] = s;
+        }
+        return y;
+    }
+    void set_from_triplets(size_t n, std::vector<std::tuple<int32_t, int32_t, T>> &trip)
+    {
+        nrows = ncols = n;
+        std::sort(trip.begin(), trip.end(), [](const auto &a, const auto &b) {
+            return std::get<0>(a) != std::get<0>(b) ? std::get<0>(a) < std::get<0>(b) : std::get<1>(a) < std::get<1>(b);
+        });
+        rowptr.assign(n + 1, 0);
+        colind.clear(); values.clear();
+        for (size_t k = 0; k < trip.size();) {
+            const int32_t r = std::get<0>(trip[k]), c = std::get<1>(trip[k]);
+            T s = 0;
+            while (k < trip.size() && std::get<0>(trip[k]) == r && std::get<1>(trip[k]) == c) s += std::get<2>(trip[k++]);
+            colind.push_back(c); values.push_back(s); rowptr[r + 1]++;
+        }
+        for (size_t i = 0; i < n; ++i) rowptr[i + 1] += rowptr[i];
+    }
+};
+
+}  // namespace proton_amd
+
+// ---------------------------------------------------------------------------------------------
+// point, mesh (basic_mesh.hpp:49-299, point.hpp)
+// ---------------------------------------------------------------------------------------------
+template <typename T, size_t DIM>
+class point {
+    std::array<T, DIM> m_coords{};
+
+  public:
+    typedef T value_type;
+    point() = default;
+    point(T x, T y) { m_coords[0] = x; m_coords[1] = y; }
+    T x() const { return m_coords[0]; }
+    T y() const { return m_coords[1]; }
+    T &x() { return m_coords[0]; }
+    T &y() { return m_coords[1]; }
+    T operator[](size_t i) const { return m_coords[i]; }
+    friend point operator+(const point &a, const point &b) { return point(a.x() + b.x(), a.y() + b.y()); }
+    friend point operator-(const point &a, const point &b) { return point(a.x() - b.x(), a.y() - b.y()); }
+    friend point operator*(const point &a, T s) { return point(a.x() * s, a.y() * s); }
+    friend point operator*(T s, const point &a) { return a * s; }
+    friend point operator/(const point &a, T s) { return point(a.x() / s, a.y() / s); }
+};
+
+enum class boundary { NONE, DIRICHLET, NEUMANN, ROBIN };
+
+template <typename T>
+struct mesh_init_params {
+    T min_x, max_x, min_y, max_y;
+    size_t Nx, Ny;
+    mesh_init_params() : min_x(0.0), max_x(1.0), min_y(0.0), max_y(1.0), Nx(4), Ny(4) {}
+    T hx() const { return (max_x - min_x) / Nx; }
+    T hy() const { return (max_y - min_y) / Ny; }
+};
+
+template <typename T>
+struct quad_mesh {
+    typedef point<T, 2> point_type;
+    typedef T coordinate_type;
+    struct cell_type {
+        std::array<size_t, 4> ptids;
+        bool operator<(const cell_type &o) const { return ptids < o.ptids; }
+        bool operator==(const cell_type &o) const { return ptids == o.ptids; }
+    };
+    struct face_type {
+        std::array<size_t, 2> ptids;
+        bool is_boundary = false;
+        boundary bndtype = boundary::NONE;
+        bool operator<(const face_type &o) const { return ptids < o.ptids; }
+        bool operator==(const face_type &o) const { return ptids == o.ptids; }
+    };
+    struct node_type { size_t ptid; };
+
+    std::vector<point_type> points;
+    std::vector<node_type> nodes;
+    std::vector<face_type> faces;
+    std::vector<cell_type> cells;
+    mesh_init_params<T> params;
+
+    quad_mesh() : quad_mesh(mesh_init_params<T>()) {}
+    // the structured generator, basic_mesh.hpp:230-298
+    explicit quad_mesh(const mesh_init_params<T> &parms) : params(parms)
+    {
+        const auto hx = parms.hx(), hy = parms.hy();
+        points.reserve((parms.Nx + 1) * (parms.Ny + 1));
+        size_t point_num = 0;
+        for (size_t j = 0; j < parms.Ny + 1; j++)
+            for (size_t i = 0; i < parms.Nx + 1; i++) {
+                points.push_back(point_type(parms.min_x + i * hx, parms.min_y + j * hy));
+                nodes.push_back(node_type{point_num++});
+            }
+        for (size_t j = 0; j < parms.Ny; j++)
+            for (size_t i = 0; i < parms.Nx; i++) {
+                const size_t p0 = j * (parms.Nx + 1) + i, p1 = p0 + 1, p2 = p0 + parms.Nx + 2, p3 = p0 + parms.Nx + 1;
+                cells.push_back(cell_type{{{p0, p1, p2, p3}}});
+                face_type f0; f0.ptids = {p0, p1}; f0.is_boundary = (j == 0);
+                face_type f1; f1.ptids = {p1, p2}; f1.is_boundary = (i == parms.Nx - 1);
+                face_type f2; f2.ptids = {p3, p2}; f2.is_boundary = (j == parms.Ny - 1);
+                face_type f3; f3.ptids = {p0, p3}; f3.is_boundary = (i == 0);
+                faces.push_back(f0); faces.push_back(f1); faces.push_back(f2); faces.push_back(f3);
+            }
+        std::sort(cells.begin(), cells.end());
+        std::sort(faces.begin(), faces.end());
+        faces.erase(std::unique(faces.begin(), faces.end()), faces.end());
+        for (auto &fc : faces)
+            if (fc.is_boundary) fc.bndtype = boundary::DIRICHLET;
+    }
+};
+
+// basic_geom.hpp:30-61
+template <typename Mesh>
+size_t offset(const Mesh &msh, const typename Mesh::cell_type &cl)
+{
+    auto itor = std::lower_bound(msh.cells.begin(), msh.cells.end(), cl);
+    if (itor == msh.cells.end()) throw std::logic_error("Cell not found: this is likely a bug.");
+    return std::distance(msh.cells.begin(), itor);
+}
+template <typename Mesh>
+size_t offset(const Mesh &msh, const typename Mesh::face_type &fc)
+{
+    auto itor = std::lower_bound(msh.faces.begin(), msh.faces.end(), fc);
+    if (itor == msh.faces.end()) throw std::logic_error("Face not found: this is likely a bug.");
+    return std::distance(msh.faces.begin(), itor);
+}
+// basic_geom.hpp:183-212
+template <typename Mesh>
+std::array<typename Mesh::face_type, 4> faces(const Mesh &msh, const typename Mesh::cell_type &cl)
+{
+    std::array<typename Mesh::face_type, 4> ret;
+    for (size_t i = 0; i < 4; i++) {
+        typename Mesh::face_type f;
+        f.ptids[0] = cl.ptids[i];
+        f.ptids[1] = cl.ptids[(i + 1) % 4];
+        if (f.ptids[0] > f.ptids[1]) std::swap(f.ptids[0], f.ptids[1]);
+        auto itor = std::lower_bound(msh.faces.begin(), msh.faces.end(), f);
+        if (itor == msh.faces.end()) throw std::logic_error("Face not found, this is likely a bug.");
+        ret[i] = *itor;
+    }
+    return ret;
+}
+template <typename Mesh>
+std::array<typename Mesh::point_type, 4> points(const Mesh &msh, const typename Mesh::cell_type &cl)
+{
+    std::array<typename Mesh::point_type, 4> ret;
+    for (size_t i = 0; i < 4; i++) ret[i] = msh.points.at(cl.ptids[i]);
+    return ret;
+}
+// basic_geom.hpp:247-305
+template <typename Mesh>
+typename Mesh::point_type barycenter(const Mesh &msh, const typename Mesh::cell_type &cl)
+{
+    typedef typename Mesh::coordinate_type T;
+    auto pts = points(msh, cl);
+    typename Mesh::point_type ret;
+    T den = 0.0;
+    for (size_t i = 2; i < 4; i++) {
+        auto pprev = pts[i - 1] - pts[0], pcur = pts[i] - pts[0];
+        auto d = (pprev.x() * pcur.y() - pprev.y() * pcur.x()) / 2.0;
+        ret = ret + (pprev + pcur) * d;
+        den += d;
+    }
+    return pts[0] + ret / (den * 3);
+}
+template <typename Mesh>
+typename Mesh::coordinate_type diameter(const Mesh &msh, const typename Mesh::cell_type &cl)
+{
+    typename Mesh::coordinate_type diam = 0.0;
+    for (size_t i = 0; i < 4; i++)
+        for (size_t j = i + 1; j < 4; j++) {
+            auto d = msh.points.at(cl.ptids[j]) - msh.points.at(cl.ptids[i]);
+            diam = std::max(diam, std::sqrt(d.x() * d.x() + d.y() * d.y()));
+        }
+    return diam;
+}
+
+// utils.hpp:62-111
+class hho_degree_info {
+    size_t cell_deg, face_deg, reconstruction_deg;
+
+  public:
+    hho_degree_info() : cell_deg(1), face_deg(1), reconstruction_deg(2) {}
+    explicit hho_degree_info(size_t degree) : cell_deg(degree), face_deg(degree), reconstruction_deg(degree + 1) {}
+    hho_degree_info(size_t cd, size_t fd)
+    {
+        int fell_back = 0;
+        const pa_degree_info d = pa_degree_info_make((int)cd, (int)fd, &fell_back);
+        if (fell_back) std::cout << "Invalid cell degree. Reverting to equal-order" << std::endl;      // utils.hpp:88
+        cell_deg = d.cell_deg; face_deg = d.face_deg; reconstruction_deg = d.rec_deg;
+    }
+    size_t cell_degree() const { return cell_deg; }
+    size_t face_degree() const { return face_deg; }
+    size_t reconstruction_degree() const { return reconstruction_deg; }
+    pa_degree_info c_abi() const { return pa_degree_info{(int32_t)cell_deg, (int32_t)face_deg, (int32_t)reconstruction_deg}; }
+};
+
+namespace proton_amd {
+
+// ---------------------------------------------------------------------------------------------
+// The batch behind the per-cell API
+// ---------------------------------------------------------------------------------------------
+template <typename Mesh>
+class mesh_on_device {
+  public:
+    const Mesh *msh = nullptr;
+    size_t npoints = 0, ncells = 0;
+    double probe = 0.0;      // cheap change detector: sum of a few coordinates
+
+    static double make_probe(const Mesh &m)
+    {
+        double s = 0.0;
+        const size_t n = m.points.size(), step = n / 16 + 1;
+        for (size_t i = 0; i < n; i += step) s += m.points[i].x() * 3.0 + m.points[i].y();
+        return s;
+    }
+    bool matches(const Mesh &m) const
+    {
+        return msh == &m && npoints == m.points.size() && ncells == m.cells.size() && probe == make_probe(m);
+    }
+    // msh.points, cell.ptids and msh.faces as the reference holds them
+    void upload(const Mesh &m)
+    {
+        auto &dev = device::instance();
+        std::vector<double> pts(2 * m.points.size());
+        for (size_t i = 0; i < m.points.size(); ++i) { pts[2 * i] = m.points[i].x(); pts[2 * i + 1] = m.points[i].y(); }
+        std::vector<uint32_t> ids(4 * m.cells.size()), cf(4 * m.cells.size());
+        for (size_t c = 0; c < m.cells.size(); ++c) {
+            auto fcs = faces(m, m.cells[c]);
+            for (int v = 0; v < 4; ++v) {
+                ids[4 * c + v] = (uint32_t)m.cells[c].ptids[v];
+                cf[4 * c + v] = (uint32_t)offset(m, fcs[v]);
+            }
+        }
+        std::vector<uint32_t> fp(2 * m.faces.size());
+        std::vector<uint8_t> fd(m.faces.size());
+        for (size_t f = 0; f < m.faces.size(); ++f) {
+            fp[2 * f] = (uint32_t)m.faces[f].ptids[0]; fp[2 * f + 1] = (uint32_t)m.faces[f].ptids[1];
+            fd[f] = (m.faces[f].is_boundary && m.faces[f].bndtype == boundary::DIRICHLET) ? 1 : 0;
+        }
+        dev.check(pa_mesh_upload(dev.ctx(), pts.data(), m.points.size(), ids.data(), m.cells.size()), "pa_mesh_upload");
+        dev.check(pa_mesh_set_faces(dev.ctx(), cf.data(), fp.data(), fd.data(), m.faces.size()), "pa_mesh_set_faces");
+        msh = &m; npoints = m.points.size(); ncells = m.cells.size(); probe = make_probe(m);
+    }
+};
+
+struct local_batch {
+    pa_sizes sz{};
+    std::vector<double> oper, data, stab;     // host copies, cell-major, column-major per cell
+    std::vector<int32_t> info;
+};
+
+template <typename Mesh>
+class batch_cache {
+    mesh_on_device<Mesh> dev_mesh_;
+    std::map<std::tuple<int, int, int, int>, std::shared_ptr<local_batch>> batches_;
+    std::map<std::tuple<int, int, int>, std::vector<double>> qpoints_;      // (degree, quad) -> n x nq x 3
+
+  public:
+    static batch_cache &instance()
+    {
+        static batch_cache c;
+        return c;
+    }
+    void ensure_mesh(const Mesh &m)
+    {
+        if (!dev_mesh_.matches(m)) {
+            batches_.clear(); qpoints_.clear();
+            dev_mesh_.upload(m);
+        }
+    }
+    void invalidate() { dev_mesh_ = mesh_on_device<Mesh>(); batches_.clear(); qpoints_.clear(); }
+
+    std::shared_ptr<local_batch> get(const Mesh &m, const hho_degree_info &hdi, int quad, int stab)
+    {
+        ensure_mesh(m);
+        const auto key = std::make_tuple((int)hdi.cell_degree(), (int)hdi.face_degree(), quad, stab);
+        auto it = batches_.find(key);
+        if (it != batches_.end()) return it->second;
+        auto &dev = device::instance();
+        auto b = std::make_shared<local_batch>();
+        dev.check(pa_sizes_for(hdi.c_abi(), quad, &b->sz), "pa_sizes_for");
+        const size_t n = m.cells.size(), mm = (size_t)b->sz.msize * b->sz.msize, om = (size_t)b->sz.oper_rows * b->sz.msize;
+        device_buffer<double> d_oper(n * om), d_data(n * mm), d_stab(n * mm);
+        device_buffer<int32_t> d_info(n);
+        dev.check(pa_local_ops_batch(dev.ctx(), hdi.c_abi(), quad, stab, 0, n, d_oper.get(), d_data.get(), d_stab.get(),
+                                     nullptr, d_info.get()), "pa_local_ops_batch");
+        b->oper.resize(n * om); b->data.resize(n * mm); b->stab.resize(n * mm); b->info.resize(n);
+        d_oper.download(b->oper.data(), n * om);
+        d_data.download(b->data.data(), n * mm);
+        d_stab.download(b->stab.data(), n * mm);
+        d_info.download(b->info.data(), n);
+        batches_[key] = b;
+        return b;
+    }
+
+    // quadrature points of integrate(msh, cl, degree) for every cell (x, y, w)
+    const std::vector<double> &cell_qpoints(const Mesh &m, int degree, int quad, int &nq)
+    {
+        ensure_mesh(m);
+        auto &dev = device::instance();
+        int32_t nqp = 0;
+        dev.check(pa_cell_quadrature_points(dev.ctx(), degree, quad, 0, 0, nullptr, &nqp), "pa_cell_quadrature_points");
+        nq = nqp;
+        const auto key = std::make_tuple(degree, quad, 0);
+        auto it = qpoints_.find(key);
+        if (it != qpoints_.end()) return it->second;
+        const size_t n = m.cells.size();
+        device_buffer<double> d(n * nqp * 3);
+        dev.check(pa_cell_quadrature_points(dev.ctx(), degree, quad, 0, n, d.get(), &nqp), "pa_cell_quadrature_points");
+        std::vector<double> h(n * nqp * 3);
+        d.download(h.data(), h.size());
+        return qpoints_[key] = std::move(h);
+    }
+};
+
+template <typename Mesh>
+inline void invalidate(const Mesh &) { batch_cache<Mesh>::instance().invalidate(); }
+
+template <typename T>
+inline dense_matrix<T> copy_cell(const std::vector<double> &src, size_t cell, size_t rows, size_t cols)
+{
+    dense_matrix<T> m(rows, cols);
+    std::memcpy(m.data(), src.data() + cell * rows * cols, rows * cols * sizeof(double));
+    return m;
+}
+
+}  // namespace proton_amd
+
+// ---------------------------------------------------------------------------------------------
+// The reference's per-cell interface
+// ---------------------------------------------------------------------------------------------
+// hho.hpp:32-35  -> pair(oper (rbs-1) x msize, data msize x msize)
+template <typename Mesh>
+std::pair<proton_amd::dense_matrix<typename Mesh::coordinate_type>, proton_amd::dense_matrix<typename Mesh::coordinate_type>>
+make_hho_laplacian(const Mesh &msh, const typename Mesh::cell_type &cl, const hho_degree_info &di)
+{
+    using T = typename Mesh::coordinate_type;
+    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, PA_QUAD_TENSOR, PA_STAB_FANCY);
+    const size_t c = offset(msh, cl);
+    return std::make_pair(proton_amd::copy_cell<T>(b->oper, c, b->sz.oper_rows, b->sz.msize),
+                          proton_amd::copy_cell<T>(b->data, c, b->sz.msize, b->sz.msize));
+}
+
+// hho.hpp:99-101
+template <typename Mesh>
+proton_amd::dense_matrix<typename Mesh::coordinate_type>
+make_hho_naive_stabilization(const Mesh &msh, const typename Mesh::cell_type &cl, const hho_degree_info &di)
+{
+    using T = typename Mesh::coordinate_type;
+    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, PA_QUAD_TENSOR, PA_STAB_NAIVE);
+    return proton_amd::copy_cell<T>(b->stab, offset(msh, cl), b->sz.msize, b->sz.msize);
+}
+
+// hho.hpp:155-159.  `reconstruction` is make_hho_laplacian(...).first of the same cell; the batch
+// recomputes it on the device, so the argument only documents the dependency.
+template <typename Mesh>
+proton_amd::dense_matrix<typename Mesh::coordinate_type>
+make_hho_fancy_stabilization(const Mesh &msh, const typename Mesh::cell_type &cl,
+                             const proton_amd::dense_matrix<typename Mesh::coordinate_type> & /*reconstruction*/,
+                             const hho_degree_info &di)
+{
+    using T = typename Mesh::coordinate_type;
+    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, PA_QUAD_TENSOR, PA_STAB_FANCY);
+    return proton_amd::copy_cell<T>(b->stab, offset(msh, cl), b->sz.msize, b->sz.msize);
+}
+
+// utils.hpp:153-156.  The functor runs on the host at the quadrature points of
+// integrate(msh, cl, 2*(degree+di)); the weighted sums run on the device (PA_FN_SAMPLED).
+template <typename Mesh, typename Function>
+proton_amd::dense_matrix<typename Mesh::coordinate_type>
+make_rhs(const Mesh &msh, const typename Mesh::cell_type &cl, size_t degree, const Function &f, size_t di = 0)
+{
+    using T = typename Mesh::coordinate_type;
+    auto &cache = proton_amd::batch_cache<Mesh>::instance();
+    auto &dev = proton_amd::device::instance();
+    int nq = 0;
+    const auto &xyw = cache.cell_qpoints(msh, (int)(2 * (degree + di)), PA_QUAD_TENSOR, nq);
+    const size_t c = offset(msh, cl);
+    std::vector<double> fv(nq);
+    for (int q = 0; q < nq; ++q) fv[q] = f(typename Mesh::point_type(xyw[(c * nq + q) * 3], xyw[(c * nq + q) * 3 + 1]));
+    const size_t cbs = (degree + 2) * (degree + 1) / 2;
+    proton_amd::device_buffer<double> d_f(nq), d_r(cbs);
+    d_f.upload(fv.data(), nq);
+    dev.check(pa_cell_rhs_batch(dev.ctx(), (int)degree, (int)di, PA_QUAD_TENSOR, PA_FN_SAMPLED, d_f.get(), c, 1, d_r.get()),
+              "pa_cell_rhs_batch");
+    proton_amd::dense_matrix<T> ret(cbs, 1);
+    d_r.download(ret.data(), cbs);
+    return ret;
+}
+
+// hho.hpp:252-463
+template <typename Mesh>
+class assembler {
+    using T = typename Mesh::coordinate_type;
+    std::vector<size_t> compress_table, expand_table;
+    hho_degree_info di;
+    std::vector<std::tuple<int32_t, int32_t, T>> triplets;
+
+    struct assembly_index {
+        size_t idx; bool assem;
+        operator size_t() const
+        {
+            if (!assem) throw std::logic_error("Invalid assembly_index");
+            return idx;
+        }
+        bool assemble() const { return assem; }
+    };
+
+    // L2 projection of the boundary function on a face: mass.llt().solve(rhs), hho.hpp:383-385,
+    // through the device entry point (one face, sampled at its Gauss points)
+    template <typename Function>
+    std::vector<T> dirichlet_projection(const Mesh &msh, size_t face_offset, const Function &bf)
+    {
+        auto &dev = proton_amd::device::instance();
+        proton_amd::batch_cache<Mesh>::instance().ensure_mesh(msh);
+        const size_t fd = di.face_degree(), fbs = fd + 1, nf = msh.faces.size();
+        if (face_xyw_.empty()) {
+            proton_amd::device_buffer<double> d(nf * fbs * 3);
+            dev.check(pa_face_quadrature_points(dev.ctx(), (int)fd, d.get()), "pa_face_quadrature_points");
+            face_xyw_.resize(nf * fbs * 3);
+            d.download(face_xyw_.data(), face_xyw_.size());
+        }
+        if (g_valid_for_ != (const void *)&bf) {      // one batch per boundary functor
+            std::vector<double> fv(nf * fbs);
+            for (size_t f = 0; f < nf; ++f)
+                for (size_t q = 0; q < fbs; ++q)
+                    fv[f * fbs + q] = bf(typename Mesh::point_type(face_xyw_[(f * fbs + q) * 3], face_xyw_[(f * fbs + q) * 3 + 1]));
+            proton_amd::device_buffer<double> d_f(nf * fbs), d_g(nf * fbs);
+            d_f.upload(fv.data(), fv.size());
+            dev.check(pa_dirichlet_data_batch(dev.ctx(), (int)fd, PA_FN_SAMPLED, d_f.get(), d_g.get()), "pa_dirichlet_data_batch");
+            g_.resize(nf * fbs);
+            d_g.download(g_.data(), g_.size());
+            g_valid_for_ = (const void *)&bf;
+        }
+        return std::vector<T>(g_.begin() + face_offset * fbs, g_.begin() + (face_offset + 1) * fbs);
+    }
+    std::vector<double> face_xyw_, g_;
+    const void *g_valid_for_ = nullptr;
+
+  public:
+    proton_amd::sparse_matrix<T> LHS;
+    std::vector<T> RHS;
+
+    assembler(const Mesh &msh, hho_degree_info hdi) : di(hdi)
+    {
+        auto is_dirichlet = [&](const typename Mesh::face_type &fc) { return fc.is_boundary && fc.bndtype == boundary::DIRICHLET; };
+        const size_t num_all_faces = msh.faces.size();
+        const size_t num_dirichlet_faces = std::count_if(msh.faces.begin(), msh.faces.end(), is_dirichlet);
+        const size_t num_other_faces = num_all_faces - num_dirichlet_faces;
+        compress_table.resize(num_all_faces);
+        expand_table.resize(num_other_faces);
+        size_t compressed_offset = 0;
+        for (size_t i = 0; i < num_all_faces; i++)
+            if (!is_dirichlet(msh.faces[i])) {
+                compress_table.at(i) = compressed_offset;
+                expand_table.at(compressed_offset) = i;
+                compressed_offset++;
+            }
+        const size_t cbs = (di.cell_degree() + 2) * (di.cell_degree() + 1) / 2, fbs = di.face_degree() + 1;
+        const size_t system_size = cbs * msh.cells.size() + fbs * num_other_faces;      // hho.hpp:331
+        LHS.nrows = LHS.ncols = system_size;
+        RHS.assign(system_size, T(0));
+    }
+
+    // hho.hpp:344-406
+    template <typename Function>
+    void assemble(const Mesh &msh, const typename Mesh::cell_type &cl, const proton_amd::dense_matrix<T> &lhs,
+                  const proton_amd::dense_matrix<T> &rhs, const Function &dirichlet_bf)
+    {
+        const size_t cbs = (di.cell_degree() + 2) * (di.cell_degree() + 1) / 2, fbs = di.face_degree() + 1;
+        auto fcs = faces(msh, cl);
+        const size_t num_faces = fcs.size();
+        std::vector<assembly_index> asm_map;
+        asm_map.reserve(cbs + num_faces * fbs);
+        const size_t cell_offset = offset(msh, cl), cell_LHS_offset = cell_offset * cbs;
+        for (size_t i = 0; i < cbs; i++) asm_map.push_back(assembly_index{cell_LHS_offset + i, true});
+        std::vector<T> dirichlet_data(cbs + num_faces * fbs, T(0));
+        for (size_t face_i = 0; face_i < num_faces; face_i++) {
+            auto fc = fcs[face_i];
+            const size_t face_offset = offset(msh, fc);
+            const bool dirichlet = fc.is_boundary && fc.bndtype == boundary::DIRICHLET;
+            const size_t face_LHS_offset = cbs * msh.cells.size() + (dirichlet ? 0 : compress_table.at(face_offset)) * fbs;
+            for (size_t i = 0; i < fbs; i++) asm_map.push_back(assembly_index{face_LHS_offset + i, !dirichlet});
+            if (dirichlet) {
+                auto g = dirichlet_projection(msh, face_offset, dirichlet_bf);
+                for (size_t i = 0; i < fbs; i++) dirichlet_data[cbs + face_i * fbs + i] = g[i];
+            }
+        }
+        assert(asm_map.size() == lhs.rows() && asm_map.size() == lhs.cols());
+        for (size_t i = 0; i < lhs.rows(); i++) {
+            if (!asm_map[i].assemble()) continue;
+            for (size_t j = 0; j < lhs.cols(); j++) {
+                if (asm_map[j].assemble())
+                    triplets.emplace_back((int32_t)(size_t)asm_map[i], (int32_t)(size_t)asm_map[j], lhs(i, j));
+                else
+                    RHS[asm_map[i]] -= lhs(i, j) * dirichlet_data[j];
+            }
+        }
+        for (size_t i = 0; i < cbs; i++) RHS[cell_LHS_offset + i] += rhs(i);
+    }
+
+    // hho.hpp:408-449
+    template <typename Function>
+    proton_amd::dense_matrix<T> take_local_data(const Mesh &msh, const typename Mesh::cell_type &cl,
+                                                 const std::vector<T> &solution, const Function &dirichlet_bf)
+    {
+        const size_t cbs = (di.cell_degree() + 2) * (di.cell_degree() + 1) / 2, fbs = di.face_degree() + 1;
+        const size_t cell_SOL_offset = offset(msh, cl) * cbs;
+        auto fcs = faces(msh, cl);
+        proton_amd::dense_matrix<T> ret(cbs + fcs.size() * fbs, 1);
+        for (size_t i = 0; i < cbs; i++) ret(i) = solution[cell_SOL_offset + i];
+        for (size_t face_i = 0; face_i < fcs.size(); face_i++) {
+            auto fc = fcs[face_i];
+            const size_t face_offset = offset(msh, fc);
+            if (fc.is_boundary && fc.bndtype == boundary::DIRICHLET) {
+                auto g = dirichlet_projection(msh, face_offset, dirichlet_bf);
+                for (size_t i = 0; i < fbs; i++) ret(cbs + face_i * fbs + i) = g[i];
+            } else {
+                const size_t face_SOL_offset = cbs * msh.cells.size() + compress_table.at(face_offset) * fbs;
+                for (size_t i = 0; i < fbs; i++) ret(cbs + face_i * fbs + i) = solution[face_SOL_offset + i];
+            }
+        }
+        return ret;
+    }
+
+    // hho.hpp:451-455: LHS.setFromTriplets (duplicates summed)
+    void finalize(void)
+    {
+        LHS.set_from_triplets(RHS.size(), triplets);
+        triplets.clear();
+    }
+
+    // Batched equivalent of the whole loop of convergence_test.cpp:202-215 with built-in source
+    // terms: local operators, right-hand sides, Dirichlet data and triplets on the device.
+    void assemble_all(const Mesh &msh, int stab_kind, int rhs_fn, int dirichlet_fn)
+    {
+        auto &dev = proton_amd::device::instance();
+        proton_amd::batch_cache<Mesh>::instance().ensure_mesh(msh);
+        pa_sizes sz;
+        dev.check(pa_sizes_for(di.c_abi(), PA_QUAD_TENSOR, &sz), "pa_sizes_for");
+        const size_t n = msh.cells.size(), ms = sz.msize, mm = ms * ms;
+        proton_amd::device_buffer<double> d_lc(n * mm), d_rhs(n * sz.cbs), d_g(msh.faces.size() * sz.fbs), d_vals(n * mm), d_rv(n * ms);
+        proton_amd::device_buffer<int32_t> d_rows(n * mm), d_cols(n * mm), d_rr(n * ms);
+        dev.check(pa_local_ops_batch(dev.ctx(), di.c_abi(), PA_QUAD_TENSOR, stab_kind, 0, n, nullptr, nullptr, nullptr, d_lc.get(), nullptr), "pa_local_ops_batch");
+        dev.check(pa_cell_rhs_batch(dev.ctx(), (int)di.cell_degree(), 0, PA_QUAD_TENSOR, rhs_fn, nullptr, 0, n, d_rhs.get()), "pa_cell_rhs_batch");
+        dev.check(pa_dirichlet_data_batch(dev.ctx(), (int)di.face_degree(), dirichlet_fn, nullptr, d_g.get()), "pa_dirichlet_data_batch");
+        dev.check(pa_triplets_batch(dev.ctx(), di.c_abi(), 0, n, d_lc.get(), d_rhs.get(), d_g.get(), d_rows.get(), d_cols.get(),
+                                    d_vals.get(), d_rr.get(), d_rv.get()), "pa_triplets_batch");
+        std::vector<int32_t> rows(n * mm), cols(n * mm), rr(n * ms);
+        std::vector<double> vals(n * mm), rv(n * ms);
+        d_rows.download(rows.data(), rows.size()); d_cols.download(cols.data(), cols.size());
+        d_vals.download(vals.data(), vals.size()); d_rr.download(rr.data(), rr.size()); d_rv.download(rv.data(), rv.size());
+        for (size_t k = 0; k < rows.size(); ++k)
+            if (rows[k] >= 0) triplets.emplace_back(rows[k], cols[k], vals[k]);
+        for (size_t k = 0; k < rr.size(); ++k)
+            if (rr[k] >= 0) RHS[rr[k]] += rv[k];
+    }
+};
+
+template <typename Mesh>
+auto make_assembler(const Mesh &msh, hho_degree_info hdi)
+{
+    return assembler<Mesh>(msh, hdi);
+}

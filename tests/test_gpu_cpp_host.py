@@ -1,0 +1,54 @@
+"""The C++ drop-in host header (proton_amd/host/hho.hpp, the reference's make_hho_* / assembler
+names) driven the way apps/convergence_test drives the reference: compiled with g++ against the C ABI
+only, run on the GPU box, compared with the all-oracle path."""
+import math
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def driver():
+    out_dir = os.path.join(ROOT, "tests", "cpp", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "convergence_driver")
+    lib_dir = os.path.join(ROOT, "proton_amd", "lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cpp", "convergence_driver.cpp"),
+           "-L" + lib_dir, "-lproton_amd", "-Wl,-rpath," + lib_dir]
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+def run(exe, *args):
+    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    errs = [float(m) for m in re.findall(r"l2_error ([0-9.e+-]+)", r.stdout)]
+    rates = [float(m) for m in re.findall(r"rate ([0-9.e+-]+)", r.stdout)]
+    return errs, rates, r.stdout
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_per_cell_api_matches_oracle_path(driver, k):
+    import poisson_driver as pd
+    errs, rates, out = run(driver, k, 4, 3)                       # N = 4, 8, 16 through the per-cell API
+    assert len(errs) == 3
+    for N, e in zip((4, 8, 16), errs):
+        LHS, RHS, asm, di = pd.oracle_assembly(N, k + 1, k)
+        ref = pd.l2_error(asm, di, pd.solve(LHS, RHS))
+        assert abs(e - ref) < 1e-7 * ref + 1e-11, (N, e, ref, out)  # CG tolerance 1e-12 on the residual
+    assert rates[-1] > k + 2 - 0.35
+
+
+def test_batched_api_same_as_per_cell(driver):
+    e1, _, _ = run(driver, 1, 8, 2)
+    e2, _, _ = run(driver, 1, 8, 2, "batched")
+    assert np.allclose(e1, e2, rtol=1e-8)
+    # config 1 of BASELINE.json: 32x32 k=1 (plumbing), batched
+    e3, r3, out = run(driver, 1, 16, 2, "batched")
+    assert r3[-1] > 2.7 and "N 32" in out
