@@ -55,22 +55,24 @@ def bytes_per_cell(msize, cbs):
     return 8 * msize * msize + 8 * cbs + 80
 
 
-def row_partition(N, world, rank):
-    return (rank * N) // world, ((rank + 1) * N) // world
-
-
-def cpu_baseline(w, sample_rows):
+def cpu_baseline(w, sample_rows, target_seconds=15.0):
     """The oracle (CPU restatement, single thread like the reference) on a bounded sample of the
-    same workload: the first `sample_rows` cell rows of the same mesh."""
+    same workload: the first `sample_rows` cell rows of the same mesh (0 = as many rows as take
+    about `target_seconds` at the rate measured on a small probe)."""
     import oracle_lib
     N = w["N"]
     mp, points, ptids = oracle_lib.make_mesh(N, N, w["lo"], w["hi"])
     di = oracle_lib.degrees(w["cd"], w["fd"])
     quad = oracle_lib.QUAD_TENSOR if w["quad"] == "tensor" else oracle_lib.QUAD_FAN
     stab = oracle_lib.STAB_FANCY if w["stab"] == "fancy" else oracle_lib.STAB_NAIVE
+    probe = min(N * N, 4096)
+    t0 = time.perf_counter()
+    oracle_lib.local_ops_batch(points, ptids, di, quad, stab, first=0, n=probe, fn=w["fn"], rhs_di=w["dinc"],
+                               want=("lc",))                       # warm-up + rate probe
+    rate = probe / (time.perf_counter() - t0)
+    if sample_rows <= 0:
+        sample_rows = max(1, min(N, int(target_seconds * rate / N)))
     n = sample_rows * N
-    oracle_lib.local_ops_batch(points, ptids, di, quad, stab, first=0, n=min(n, 2048), fn=w["fn"], rhs_di=w["dinc"],
-                               want=("lc",))                       # warm-up
     t0 = time.perf_counter()
     st, _ = oracle_lib.local_ops_batch(points, ptids, di, quad, stab, first=0, n=n, fn=w["fn"], rhs_di=w["dinc"],
                                        want=("lc",))
@@ -97,6 +99,7 @@ def main():
     import torch.distributed as dist
     import proton_amd as pa
     from proton_amd.batch import BatchAssembler
+    from proton_amd.partition import CondensedExchange, cell_counts, condensed_per_cell, row_partition
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -131,10 +134,8 @@ def main():
     exchange = world > 1 and args.exchange == "allgather"
     if exchange:
         nf = 4 * sz.fbs
-        per_cell = nf * nf + nf                     # S (values only) + g
-        counts = [(row_partition(N, world, r)[1] - row_partition(N, world, r)[0]) * N for r in range(world)]
-        gathered = [torch.empty(c * per_cell, dtype=torch.float64, device=dev) for c in counts]
-        mine = torch.empty(n_local * per_cell, dtype=torch.float64, device=dev)
+        ex = CondensedExchange(cell_counts(N, N, world), condensed_per_cell(sz.fbs), rank, dev)
+        mine = ex.local_view()
         S_view = mine[: n_local * nf * nf]
         g_view = mine[n_local * nf * nf:]
 
@@ -151,7 +152,7 @@ def main():
         if exchange:
             asm.ctx.static_condensation(di, n_local, lc.data_ptr(), rhs.data_ptr(), S_view.data_ptr(), g_view.data_ptr(),
                                         None, None)
-            dist.all_gather(gathered, mine)
+            ex.exchange()
 
     for _ in range(args.warmup):
         step()
@@ -215,11 +216,7 @@ def main():
             "kernel_only_cells_per_s": total_cells / (kern_ms * 1e-3) if world == 1 else n_local * world / (kern_ms * 1e-3),
         }
         if not args.no_cpu_baseline and world == 1:
-            rows = args.cpu_sample_rows
-            if rows <= 0:       # ~15 s of single-thread CPU work, measured rate of the oracle: 60 / 18 / 105 us per cell
-                per_cell_us = {1: 18.0, 2: 60.0, 3: 105.0}.get(w["fd"], 60.0)
-                rows = max(1, min(N, int(15e6 / per_cell_us / N)))
-            res["cpu_baseline"] = cpu_baseline(w, rows)
+            res["cpu_baseline"] = cpu_baseline(w, args.cpu_sample_rows)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
         else:
             res["cpu_baseline"] = None

@@ -1,0 +1,47 @@
+"""Multi-GPU plumbing of the hot path: block row partition of the structured mesh and the one
+exchange step (all_gather of the condensed face-dof blocks before the host-side solve).
+Backend-agnostic: `nccl` (= RCCL over xGMI) on GPUs, `gloo` in the CPU tests."""
+import torch
+import torch.distributed as dist
+
+
+def row_partition(N, world, rank):
+    """Cell rows [r0, r1) of rank `rank`: contiguous blocks, sizes differ by at most one row."""
+    return (rank * N) // world, ((rank + 1) * N) // world
+
+
+def cell_counts(Nx, Ny, world):
+    return [(row_partition(Ny, world, r)[1] - row_partition(Ny, world, r)[0]) * Nx for r in range(world)]
+
+
+def condensed_per_cell(fbs):
+    """values exchanged per cell: S (4 fbs)^2 (values only, indices are closed-form) + g (4 fbs)"""
+    nf = 4 * fbs
+    return nf * nf + nf
+
+
+class CondensedExchange:
+    """Preallocated buffers for the per-step all_gather; ranks may own different numbers of cells
+    (the send buffer is padded to the largest block, the result is compacted by views)."""
+
+    def __init__(self, counts, per_cell, rank, device, dtype=torch.float64):
+        self.counts, self.per_cell, self.rank = list(counts), per_cell, rank
+        self.world = len(counts)
+        self.slot = max(counts) * per_cell
+        self.send = torch.zeros(self.slot, dtype=dtype, device=device)
+        self.recv = torch.empty(self.world * self.slot, dtype=dtype, device=device)
+
+    def local_view(self):
+        """where this rank writes its n_local * per_cell values before exchange()"""
+        return self.send[: self.counts[self.rank] * self.per_cell]
+
+    def exchange(self):
+        if self.world == 1:
+            self.recv[: self.slot].copy_(self.send)
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send)
+        return self.recv
+
+    def gathered(self, r):
+        """view of rank r's block [counts[r], per_cell] after exchange()"""
+        return self.recv[r * self.slot: r * self.slot + self.counts[r] * self.per_cell].view(self.counts[r], self.per_cell)
