@@ -135,9 +135,7 @@ def main():
     if exchange:
         nf = 4 * sz.fbs
         ex = CondensedExchange(cell_counts(N, N, world), condensed_per_cell(sz.fbs), rank, dev)
-        mine = ex.local_view()
-        S_view = mine[: n_local * nf * nf]
-        g_view = mine[n_local * nf * nf:]
+        S_view, g_view = ex.local_S_g(nf)
 
     k_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     k_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]

@@ -35,6 +35,17 @@ class CondensedExchange:
         """where this rank writes its n_local * per_cell values before exchange()"""
         return self.send[: self.counts[self.rank] * self.per_cell]
 
+    def local_S_g(self, nf):
+        """the layout the condensation kernel writes: all S blocks [n, nf, nf], then all g [n, nf]"""
+        n = self.counts[self.rank]
+        v = self.local_view()
+        return v[: n * nf * nf].view(n, nf, nf), v[n * nf * nf:].view(n, nf)
+
+    def gathered_S_g(self, r, nf):
+        n = self.counts[r]
+        v = self.recv[r * self.slot: r * self.slot + n * self.per_cell]
+        return v[: n * nf * nf].view(n, nf, nf), v[n * nf * nf:].view(n, nf)
+
     def exchange(self):
         if self.world == 1:
             self.recv[: self.slot].copy_(self.send)

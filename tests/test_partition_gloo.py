@@ -30,14 +30,13 @@ def _condensed_blocks(N, cd, fd, first, n):
     di = o.degrees(cd, fd)
     st, out = o.local_ops_batch(points, ptids, di, o.QUAD_TENSOR, o.STAB_FANCY, first=first, n=n, fn=1, want=("lc",))
     assert st == 0
-    per = condensed_per_cell(di.fbs)
     nf = 4 * di.fbs
-    blk = np.zeros((n, per))
+    Sb, gb = np.zeros((n, nf, nf)), np.zeros((n, nf))
     for c in range(n):
         st, S, g, rec = o.static_condensation(out["lc"][c], out["rhs"][c], di.cbs)
-        blk[c, : nf * nf] = S.T.reshape(-1)          # column-major, as the device kernel writes it
-        blk[c, nf * nf:] = g
-    return blk
+        Sb[c] = S.T                                  # column-major, as the device kernel writes it
+        gb[c] = g
+    return Sb, gb
 
 
 def _worker(rank, world, port, N, cd, fd, q):
@@ -51,12 +50,16 @@ def _worker(rank, world, port, N, cd, fd, q):
         counts = cell_counts(N, N, world)
         r0, r1 = row_partition(N, world, rank)
         ex = CondensedExchange(counts, per, rank, torch.device("cpu"))
-        mine = _condensed_blocks(N, cd, fd, r0 * N, (r1 - r0) * N)
-        ex.local_view().copy_(torch.from_numpy(mine.reshape(-1)))
+        nf = 4 * di.fbs
+        Sb, gb = _condensed_blocks(N, cd, fd, r0 * N, (r1 - r0) * N)
+        S_view, g_view = ex.local_S_g(nf)
+        S_view.copy_(torch.from_numpy(Sb))
+        g_view.copy_(torch.from_numpy(gb))
         dist.barrier()
         ex.exchange()
-        full = torch.cat([ex.gathered(r) for r in range(world)], dim=0).numpy()
-        q.put((rank, full))
+        fullS = torch.cat([ex.gathered_S_g(r, nf)[0] for r in range(world)], dim=0).numpy()
+        fullg = torch.cat([ex.gathered_S_g(r, nf)[1] for r in range(world)], dim=0).numpy()
+        q.put((rank, (fullS, fullg)))
     finally:
         dist.destroy_process_group()
 
@@ -76,7 +79,7 @@ def test_two_rank_exchange_matches_single_process(N, cd, fd):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    ref = _condensed_blocks(N, cd, fd, 0, N * N)
+    refS, refg = _condensed_blocks(N, cd, fd, 0, N * N)
     for r in range(world):
-        assert results[r].shape == ref.shape
-        assert np.array_equal(results[r], ref)          # every rank holds the full set, in global cell order
+        assert np.array_equal(results[r][0], refS)       # every rank holds the full set, in global cell order
+        assert np.array_equal(results[r][1], refg)
