@@ -32,6 +32,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
+#ifndef PA_WAVES_PER_EU
+#define PA_WAVES_PER_EU 3
+#endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
 #else
@@ -101,23 +105,25 @@ struct Cfg {
     static constexpr int LD = (RBS + 1) & ~1;                 // stride of the (symmetric) stiffness matrix
     static constexpr int ZR = NRP + (HAS_STAB ? NF : 0);      // rows of Z = [Y; pad; U]
     static constexpr int ZS = ((ZR + 1) & ~1) % 4 == 2 ? ((ZR + 1) & ~1) : ((ZR + 1) & ~1) + 2;   // even, ZS/2 odd
+    // region Q: quadrature-point tables and moments -- dead once the gr_rhs columns are in registers
+    // (after S3b); Z = [Y; U] and later the output image reuse it.
     static constexpr int oWPX = 0;                            // NQ x NPW   w * bx^e
     static constexpr int oPY = oWPX + NQ * NPW;               // NQ x NPW   by^e
     static constexpr int oPHF = oPY + NQ * NPW;               // NFP x RBS  phi at face points
     static constexpr int oDN = (oPHF + NFP * RBS + 1) & ~1;   // NFP x NRP  (w_q/2) (grad phi . edge normal)
     static constexpr int oMOM = oDN + NFP * NRP;              // NMOM moments
-    // stiffness, stride LD; its [1:,1:] block becomes chol(gr_lhs) row by row: oST is odd so that
-    // the block (and every row of it) starts on a 16-byte boundary
-    static constexpr int oST = ((oMOM + NMOM) | 1);
+    static constexpr int endQ = oMOM + NMOM;
+    static constexpr int oZ = 0;                              // ZS x MS    (written from S5 on)
+    static constexpr int oOUT = 0;                            // MS x MS    (written in S8, after the last read of Z)
+    static constexpr int sizeQ = imax(imax(endQ, ZS * MS), MS * MS);
+    // region P: lives until the forward substitutions are done.  Stiffness, stride LD; its [1:,1:]
+    // block becomes chol(gr_lhs) row by row: oST is odd so that the block (and every row of it)
+    // starts on a 16-byte boundary
+    static constexpr int oST = sizeQ | 1;
     static constexpr int oMA = (oST + LD * RBS + 1) & ~1;     // RBS x RBS  mass (general fancy); chol(M1) in place
     static constexpr int oFT = oMA + (GENERAL_FANCY ? LD * RBS : 0);     // NF x RBS trace / (|F|/2) (general fancy)
     static constexpr int oSU = (oFT + (GENERAL_FANCY ? NF * RBS : 0) + 1) & ~1;   // 4: sqrt(|F| / 2h)
-    static constexpr int endA = oSU + 4;
-    // the LDS image of the output matrix aliases region A (dead once Z is complete)
-    static constexpr int oOUT = 0;
-    static constexpr int sizeA = (imax(endA, MS * MS) + 1) & ~1;
-    static constexpr int oZ = sizeA;                          // ZS x MS
-    static constexpr int LDS_PER_CELL = (oZ + ZS * MS + 1) & ~1;
+    static constexpr int LDS_PER_CELL = (oSU + 4 + 1) & ~1;
     static constexpr int LDS_DOUBLES = CPW * LDS_PER_CELL;
 };
 
@@ -310,8 +316,10 @@ __device__ __forceinline__ uint32_t sel4u(uint32_t v0, uint32_t v1, uint32_t v2,
 // -------------------------------------------------------------------------------------
 // The kernel.  One wavefront per block; G lanes per cell; persistent over cells.
 // -------------------------------------------------------------------------------------
-template <class C>
-__global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
+// SPLIT = false: only lc = data + stab is produced (one accumulator per entry);
+// SPLIT = true:  data and stab are kept apart so that any of lc / data / stab can be written.
+template <class C, bool SPLIT>
+__global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(LocalOpsArgs a)
 {
     constexpr int G = C::G, RBS = C::RBS, CBS = C::CBS, FBS = C::FBS, MS = C::MS, NR = C::NR, NF = C::NF;
     constexpr int NQ = C::NQ, NFQ = C::NFQ, NFP = C::NFP, NP = C::NP, RD = C::RD, NPW = C::NPW;
@@ -718,32 +726,40 @@ __global__ __launch_bounds__(64) void hho_local_ops_kernel(LocalOpsArgs a)
 
         // ================= S7: lc = Z^T Z, entries (c, c + d mod MS) ==================
         PA_MARK("S7");
-        double acc_d[ND], acc_s[ND];
+        double acc_d[ND], acc_s[SPLIT ? ND : 1];
         {
             int cp = c;
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const double *zc = S + C::oZ + cp * ZS;
-                double s = lds_dotadd<NR>(0.0, zc, ycol), u = 0.0;
-                if (C::HAS_STAB) u = lds_dotadd<NF>(0.0, zc + NRP, ucol);
-                asm volatile("" : "+v"(s), "+v"(u));     // pin: keep the FMAs next to their LDS reads
-                acc_d[d] = s; acc_s[d] = u;
+                double s = lds_dotadd<NR>(0.0, zc, ycol);
+                if (SPLIT) {
+                    double u = 0.0;
+                    if (C::HAS_STAB) u = lds_dotadd<NF>(0.0, zc + NRP, ucol);
+                    asm volatile("" : "+v"(s), "+v"(u));     // pin: keep the FMAs next to their LDS reads
+                    acc_d[d] = s; acc_s[d] = u;
+                } else {
+                    if (C::HAS_STAB) s = lds_dotadd<NF>(s, zc + NRP, ucol);
+                    asm volatile("" : "+v"(s));
+                    acc_d[d] = s;
+                }
                 cp = (cp + 1 == MS) ? 0 : cp + 1;
             }
         }
-        __syncthreads();      // every read of L (region A) and Z is done: region A becomes the output image
+        __syncthreads();      // every read of L and Z is done: the output image may overwrite Z
 
         // ================= S8: mirror through LDS, stream to HBM ======================
         PA_MARK("S8");
 #pragma unroll
-        for (int which = 0; which < 3; ++which) {
+        for (int which = 0; which < (SPLIT ? 3 : 1); ++which) {
             double *dst = which == 0 ? a.lc : which == 1 ? a.data : a.stab;
             if (dst == nullptr) continue;
             if (l < MS) {
                 int cp = c;
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
-                    const double v = which == 0 ? acc_d[d] + acc_s[d] : which == 1 ? acc_d[d] : acc_s[d];
+                    double v = acc_d[d];
+                    if (SPLIT) v = which == 0 ? acc_d[d] + acc_s[d] : which == 1 ? acc_d[d] : acc_s[d];
                     S[C::oOUT + c + cp * MS] = v;
                     S[C::oOUT + cp + c * MS] = v;
                     cp = (cp + 1 == MS) ? 0 : cp + 1;

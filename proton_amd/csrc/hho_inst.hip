@@ -10,8 +10,9 @@
 #define PA_STR(x) PA_STR2(x)
 #define PA_CAT5(a, b, c, d, e) pa_entries_##a##_##b##_##c
 #define PA_ENTRY(STAB, G)                                                                          \
-    {PA_CD, PA_FD, PA_QUAD, STAB, G, &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>>, \
-     (const void *)&pa::hho_local_ops_kernel<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>>,              \
+    {PA_CD, PA_FD, PA_QUAD, STAB, G, &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, false>, \
+     &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, true>,                           \
+     (const void *)&pa::hho_local_ops_kernel<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, false>,        \
      (int)(pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::LDS_DOUBLES * sizeof(double)),                  \
      "hho_local_ops<cd=" PA_STR(PA_CD) ",fd=" PA_STR(PA_FD) ",quad=" PA_STR(PA_QUAD) ",stab=" #STAB ",G=" #G ">"}
 #define PA_ENTRIES_G(G) PA_ENTRY(0, G), PA_ENTRY(1, G), PA_ENTRY(2, G)
@@ -19,11 +20,12 @@
 static const pa::KernelEntry k_entries[] = {
 #if PA_GMIN <= 16
     PA_ENTRIES_G(16),
-#endif
-#if PA_GMIN <= 32
+    PA_ENTRIES_G(32)
+#else
     PA_ENTRIES_G(32),
+    PA_ENTRIES_G(64)
 #endif
-    PA_ENTRIES_G(64)};
+};
 
 #define PA_FN2(cd, fd, q) pa_entries_##cd##_##fd##_##q
 #define PA_FN(cd, fd, q) PA_FN2(cd, fd, q)

@@ -9,16 +9,17 @@ typedef hipError_t (*local_ops_launcher)(const LocalOpsArgs &, int grid, hipStre
 
 struct KernelEntry {
     int cd, fd, quad, stab, lanes_per_cell;
-    local_ops_launcher launch;
+    local_ops_launcher launch;        // lc only
+    local_ops_launcher launch_split;  // any of lc / data / stab
     const void *func;          // for the occupancy query
     int lds_bytes;
     const char *name;
 };
 
-template <class C>
+template <class C, bool SPLIT>
 hipError_t launch_local_ops(const LocalOpsArgs &a, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(hho_local_ops_kernel<C>, dim3(grid), dim3(64), C::LDS_DOUBLES * sizeof(double), s, a);
+    hipLaunchKernelGGL((hho_local_ops_kernel<C, SPLIT>), dim3(grid), dim3(64), C::LDS_DOUBLES * sizeof(double), s, a);
     return hipGetLastError();
 }
 
