@@ -175,7 +175,8 @@ def main():
 
     # sanity: the timed work produced finite local matrices (not a cached / skipped result)
     probe = lc[:: max(1, n_local // 64)]
-    assert bool(torch.isfinite(probe).all()) and float(probe.abs().max()) > 0.0
+    if not os.environ.get("PA_ABLATE"):      # (profiling-only stage ablation produces garbage on purpose)
+        assert bool(torch.isfinite(probe).all()) and float(probe.abs().max()) > 0.0
 
     if rank == 0:
         total_cells = N * N

@@ -17,6 +17,8 @@ OBJ_DIR = os.path.join(HERE, "lib", "obj")
 LIB_PATH = os.path.join(HERE, "lib", "libproton_amd.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+if os.environ.get("PA_WAVES_PER_EU"):      # tuning knob: register budget of the local-operator kernel
+    FLAGS.append("-DPA_WAVES_PER_EU=" + os.environ["PA_WAVES_PER_EU"])
 
 
 def hipcc():

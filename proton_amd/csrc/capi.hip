@@ -461,6 +461,8 @@ int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int st
     a.tab = ctx->d_tab; a.points = ctx->d_points; a.ptids = ctx->d_ptids;
     a.first = first; a.n = n;
     a.oper = d_oper; a.data = d_data; a.stab = d_stab; a.lc = d_lc; a.info = d_info;
+    a.ablate = 0;
+    if (const char *env = std::getenv("PA_ABLATE")) a.ablate = (uint32_t)std::strtoul(env, nullptr, 0);   // profiling only
     const bool split = d_data != nullptr || d_stab != nullptr;
     PA_HIP(ctx, (split ? e->launch_split : e->launch)(a, grid, ctx->stream));
     return PA_OK;

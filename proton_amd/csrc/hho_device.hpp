@@ -134,6 +134,7 @@ struct LocalOpsArgs {
     size_t first, n;
     double *oper, *data, *stab, *lc;
     int32_t *info;
+    uint32_t ablate;           // debug/profiling only (PA_ABLATE): bit i skips stage i; results are then garbage
 };
 
 // index of the monomial bx^p by^r in the graded ordering (total degree, then r)  bases.hpp:114-128
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(Loca
 
         // ================= S1: evaluation points ======================================
         PA_MARK("S1");
+        if (!(a.ablate & 1u)) {   // S1
 #pragma unroll
         for (int r = 0; r < C::PPL; ++r) {
             const int p = l + r * G;
@@ -542,10 +544,12 @@ __global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(Loca
                 }
             }
         }
+        }
         __syncthreads();
 
         // ================= S2: cell moments ===========================================
         PA_MARK("S2");
+        if (!(a.ablate & 2u)) {   // S2
 #pragma unroll
         for (int t = 0; t < C::MPL; ++t) {
             if (l + t * G < C::NMOM) {
@@ -554,6 +558,7 @@ __global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(Loca
                 for (int q = 0; q < NQ; ++q) s += S[mom_ox[t] + q * NPW] * S[mom_oy[t] + q * NPW];
                 S[C::oMOM + l + t * G] = s;
             }
+        }
         }
         __syncthreads();
 
@@ -586,7 +591,10 @@ __global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(Loca
         PA_MARK("S3b");
         const int c = l < MS ? l : 0;
         double col[NR];
-        if (l < CBS) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) col[i] = 1.0;
+        if (a.ablate & 4u) {
+        } else if (l < CBS) {
             // stiff[1:, c] (contiguous, aligned) minus sum_pf (w dphi.n)[pf][:] phi_c(x_pf)
             const double *stc = S + C::oST + 1 + c * LD;
 #pragma unroll
@@ -626,7 +634,9 @@ __global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(Loca
         // Point q of face f IS the reference's q-th face point (S1 mirrors t for faces whose lower-id
         // endpoint comes second), so its face-basis value is t_q^k for either orientation.
         double ucol[C::HAS_STAB ? NF : 1];
-        if (C::HAS_STAB) {
+#pragma unroll
+        for (int r = 0; r < (C::HAS_STAB ? NF : 1); ++r) ucol[r] = 1.0;
+        if (C::HAS_STAB && !(a.ablate & 32u)) {
             constexpr int TCOLS = C::GENERAL_FANCY ? RBS : CBS;
             const int m = l < TCOLS ? l : 0;
 #pragma unroll
@@ -649,8 +659,9 @@ __global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(Loca
         // ================= S4/S5: L L^T = gr_lhs (in place in ST[1:,1:]) ; Y = L^-1 gr_rhs  hho.hpp:63,92
         PA_MARK("S4");
         double *LG = S + C::oST + 1 + LD;        // stiff[1:,1:], symmetric: row-major == column-major
-        int bad = lds_cholesky<NR, LD, G>(LG, l);
-        lds_forward<NR, LD>(LG, col);
+        int bad = 0;
+        if (!(a.ablate & 8u)) bad = lds_cholesky<NR, LD, G>(LG, l);
+        if (!(a.ablate & 16u)) lds_forward<NR, LD>(LG, col);
         if (l < MS) {
 #pragma unroll
             for (int k = 0; k < NR; ++k) S[C::oZ + k + c * ZS] = col[k];
@@ -670,7 +681,7 @@ __global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(Loca
 
         // ================= S6: column c of U ==========================================
         PA_MARK("S6");
-        if (C::HAS_STAB) {
+        if (C::HAS_STAB && !(a.ablate & 32u)) {
             if (C::GENERAL_FANCY) {
                 // proj1[:, c] = e_c - M1^-1 (M2 R[:, c])   hho.hpp:184-190
                 double pr[CBS];
@@ -724,10 +735,95 @@ __global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(Loca
         }
         __syncthreads();
 
+        // ================= S7/S8 (lc only): lc = Z^T Z on the matrix pipe ============
+        // v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) B(4x16); lane l supplies A[l&15][l>>4] and
+        // B[l>>4][l&15] and receives D[(l>>4) + 4r][l&15], r = 0..3.  For a tile (I, J) of Z^T Z both
+        // operands are elements of Z: A[i][k] = Z[k][16I+i], B[k][j] = Z[k][16J+j] -- one LDS read per
+        // lane feeds 16 FMAs (the vector form reads one LDS double per FMA).  All 64 lanes work on one
+        // cell at a time; the CPW cells of the wavefront are processed in turn.
+        if (!SPLIT) {
+            PA_MARK("S7m");
+            constexpr int NTL = (MS + 15) / 16;              // column tiles
+            constexpr int KS = (C::ZR + 3) / 4;              // k-steps
+            constexpr int NPAIRS = NTL * (NTL + 1) / 2;
+            typedef double v4d __attribute__((ext_vector_type(4)));
+            const int kk = lane >> 4, jj = lane & 15;
+            // no barrier is needed between the cells: the wavefront reads a cell's Z and then overwrites
+            // it with the same cell's output image in program order
+            __syncthreads();      // Z complete (all columns written)
+#pragma unroll
+            for (int gi = 0; gi < C::CPW; ++gi) {
+                v4d acc[NPAIRS];
+                const double *Zg = smem + gi * C::LDS_PER_CELL + C::oZ;
+                double *Og = smem + gi * C::LDS_PER_CELL + C::oOUT;
+#pragma unroll
+                for (int t = 0; t < NPAIRS; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+                if (!(a.ablate & 64u)) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const int k = 4 * ks + kk;
+                        double z[NTL];
+#pragma unroll
+                        for (int t = 0; t < NTL; ++t) {
+                            const int col = 16 * t + jj;
+                            const bool ok = k < C::ZR && col < MS;
+                            const double v = Zg[ok ? k + col * ZS : 0];
+                            z[t] = ok ? v : 0.0;
+                        }
+                        int t = 0;
+#pragma unroll
+                        for (int I = 0; I < NTL; ++I)
+#pragma unroll
+                            for (int J = I; J < NTL; ++J, ++t)
+                                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[I], z[J], acc[t], 0, 0, 0);
+                    }
+                }
+                PA_MARK("S8m");
+                if (a.lc != nullptr && !(a.ablate & 128u)) {
+                    int t = 0;
+#pragma unroll
+                    for (int I = 0; I < NTL; ++I)
+#pragma unroll
+                        for (int J = I; J < NTL; ++J, ++t) {
+                            const int colj = 16 * J + jj;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = 16 * I + kk + 4 * r;
+                                if (row < MS && colj < MS) {
+                                    const double v = acc[t][r];
+                                    Og[row + colj * MS] = v;
+                                    if (I != J) Og[colj + row * MS] = v;
+                                }
+                            }
+                        }
+                }
+            }
+            if (a.lc != nullptr && !(a.ablate & 128u)) {
+                __syncthreads();
+                if (valid) {
+                    double *o = a.lc + (cell - a.first) * (size_t)(MS * MS);
+                    constexpr int NPAIR = MS * MS / 2;
+#pragma unroll
+                    for (int e0 = 0; e0 < NPAIR; e0 += G) {
+                        const int e = e0 + l;
+                        if (e < NPAIR) {
+                            const double2 v = *reinterpret_cast<const double2 *>(S + C::oOUT + 2 * e);
+                            *reinterpret_cast<double2 *>(o + 2 * e) = v;
+                        }
+                    }
+                    if ((MS * MS) & 1) {
+                        if (l == 0) o[MS * MS - 1] = S[C::oOUT + MS * MS - 1];
+                    }
+                }
+            }
+            __syncthreads();
+        } else {
         // ================= S7: lc = Z^T Z, entries (c, c + d mod MS) ==================
         PA_MARK("S7");
         double acc_d[ND], acc_s[SPLIT ? ND : 1];
-        {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) { acc_d[d] = 1.0; if (SPLIT) acc_s[d] = 1.0; }
+        if (!(a.ablate & 64u)) {
             int cp = c;
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
@@ -753,7 +849,7 @@ __global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(Loca
 #pragma unroll
         for (int which = 0; which < (SPLIT ? 3 : 1); ++which) {
             double *dst = which == 0 ? a.lc : which == 1 ? a.data : a.stab;
-            if (dst == nullptr) continue;
+            if (dst == nullptr || (a.ablate & 128u)) continue;
             if (l < MS) {
                 int cp = c;
 #pragma unroll
@@ -782,6 +878,7 @@ __global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(Loca
                 }
             }
             __syncthreads();
+        }
         }
         if (valid && a.info != nullptr && l == 0) a.info[cell - a.first] = bad;
     }
