@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libproton_amd.so")
+LIB_PATH = os.environ.get("PA_LIB") or os.path.join(HERE, "lib", "libproton_amd.so")   # PA_LIB: A/B tuning builds
 
 QUAD_TENSOR, QUAD_FAN = 0, 1
 STAB_NONE, STAB_NAIVE, STAB_FANCY = 0, 1, 2

@@ -32,9 +32,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
+// minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__
+// argument); 0 = per configuration (Cfg::WAVES)
 #ifndef PA_WAVES_PER_EU
-#define PA_WAVES_PER_EU 3
+#define PA_WAVES_PER_EU 0
 #endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
@@ -95,6 +96,9 @@ struct Cfg {
     static constexpr int MPL = cdiv(NMOM, G);                 // moments per lane
     static constexpr int SPL = cdiv(RBS * RBS, G);            // stiffness entries per lane
     static constexpr int ND = MS / 2 + 1;                     // rotations of the symmetric update
+    // register budget: the k = 3 kernels need > 168 VGPRs to run without spills (measured: 2 waves/SIMD
+    // without spills beat 3 with), the others fit 3 waves/SIMD
+    static constexpr int WAVES = PA_WAVES_PER_EU ? PA_WAVES_PER_EU : (MS > 24 ? 2 : 3);
     static constexpr bool HAS_STAB = STAB != STAB_NONE;
     static constexpr bool FANCY = STAB == STAB_FANCY, NAIVE = STAB == STAB_NAIVE;
     static constexpr bool GENERAL_FANCY = FANCY && CD != RD;  // T_F is dense; otherwise T_F = [trace_F | 0]
@@ -123,7 +127,8 @@ struct Cfg {
     static constexpr int oMA = (oST + LD * RBS + 1) & ~1;     // RBS x RBS  mass (general fancy); chol(M1) in place
     static constexpr int oFT = oMA + (GENERAL_FANCY ? LD * RBS : 0);     // NF x RBS trace / (|F|/2) (general fancy)
     static constexpr int oSU = (oFT + (GENERAL_FANCY ? NF * RBS : 0) + 1) & ~1;   // 4: sqrt(|F| / 2h)
-    static constexpr int LDS_PER_CELL = (oSU + 4 + 1) & ~1;
+    static constexpr int oDUMMY = oSU + 4;                    // 2: sink of masked-out stores
+    static constexpr int LDS_PER_CELL = (oDUMMY + 2 + 1) & ~1;
     static constexpr int LDS_DOUBLES = CPW * LDS_PER_CELL;
 };
 
@@ -149,11 +154,12 @@ __device__ __forceinline__ void mono_exps(int m, int &p, int &r)
 }
 
 // 1/sqrt(x), 1/x, sqrt(x) for x > 0: hardware seed (~2^-26) + two Newton steps, <= 1 ulp
+template <int ITERS = 2>
 __device__ __forceinline__ double fast_rsqrt(double x)
 {
     double y = __builtin_amdgcn_rsq(x);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < ITERS; ++it) {
         const double t = x * y;
         const double e = __builtin_fma(-t, y, 1.0);
         y = __builtin_fma(0.5 * y, e, y);
@@ -172,7 +178,7 @@ __device__ __forceinline__ double fast_rcp(double x)
 }
 __device__ __forceinline__ double fast_sqrt(double x)
 {
-    const double y = fast_rsqrt(x);
+    const double y = fast_rsqrt<2>(x);
     const double s = x * y;
     const double r = __builtin_fma(-s, s, x);
     return __builtin_fma(0.5 * y, r, s);
@@ -244,7 +250,7 @@ __device__ __forceinline__ int lds_cholesky(double *A, int l)
         const double s = j == 0 ? row[0] : lds_dotsub_n(row[j], A + j * LD, row, j);
         const double d = __shfl(s, j, G);
         if (!(d > 0.0) && !bad) bad = j + 1;
-        const double r = fast_rsqrt(d);
+        const double r = fast_rsqrt<1>(d);      // seed 2^-26 -> ~3e-16 after one Newton step
         row[j] = s * r;
         if (act && l >= j) A[i * LD + j] = (l == j) ? r : row[j];
         __syncthreads();
@@ -320,7 +326,7 @@ __device__ __forceinline__ uint32_t sel4u(uint32_t v0, uint32_t v1, uint32_t v2,
 // SPLIT = false: only lc = data + stab is produced (one accumulator per entry);
 // SPLIT = true:  data and stab are kept apart so that any of lc / data / stab can be written.
 template <class C, bool SPLIT>
-__global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(LocalOpsArgs a)
+__global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArgs a)
 {
     constexpr int G = C::G, RBS = C::RBS, CBS = C::CBS, FBS = C::FBS, MS = C::MS, NR = C::NR, NF = C::NF;
     constexpr int NQ = C::NQ, NFQ = C::NFQ, NFP = C::NFP, NP = C::NP, RD = C::RD, NPW = C::NPW;
@@ -474,15 +480,17 @@ __global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(Loca
                 const bool is_cell = p < NQ;
                 if (is_cell) {
                     if (C::QUAD == QUAD_TENSOR) {
-                        const double xi = r0[r], eta = r1[r];      // quadratures.hpp:331-352
-                        x = 0.25 * px0 * (1 - xi) * (1 - eta) + 0.25 * px1 * (1 + xi) * (1 - eta) +
-                            0.25 * px2 * (1 + xi) * (1 + eta) + 0.25 * px3 * (1 - xi) * (1 + eta);
-                        y = 0.25 * py0 * (1 - xi) * (1 - eta) + 0.25 * py1 * (1 + xi) * (1 - eta) +
-                            0.25 * py2 * (1 + xi) * (1 + eta) + 0.25 * py3 * (1 - xi) * (1 + eta);
-                        const double j11 = 0.25 * ((px1 - px0) * (1 - eta) + (px2 - px3) * (1 + eta));
-                        const double j12 = 0.25 * ((py1 - py0) * (1 - eta) + (py2 - py3) * (1 + eta));
-                        const double j21 = 0.25 * ((px3 - px0) * (1 - xi) + (px2 - px1) * (1 + xi));
-                        const double j22 = 0.25 * ((py3 - py0) * (1 - xi) + (py2 - py1) * (1 + xi));
+                        // bilinear map and |det J| (quadratures.hpp:331-352) with the shape functions
+                        // 0.25 (1 +- xi)(1 +- eta) factored once
+                        double xi = r0[r], eta = r1[r];
+                        asm volatile("" : "+v"(xi), "+v"(eta));      // keep the shape functions out of LICM's reach
+                        const double am = 0.25 * (1 - eta), ap = 0.25 * (1 + eta);
+                        const double bm = 0.25 * (1 - xi), bp = 0.25 * (1 + xi);
+                        const double n0 = (1 - xi) * am, n1 = (1 + xi) * am, n2 = (1 + xi) * ap, n3 = (1 - xi) * ap;
+                        x = n0 * px0 + n1 * px1 + n2 * px2 + n3 * px3;
+                        y = n0 * py0 + n1 * py1 + n2 * py2 + n3 * py3;
+                        const double j11 = e0x * am - e2x * ap, j12 = e0y * am - e2y * ap;
+                        const double j21 = e1x * bp - e3x * bm, j22 = e1y * bp - e3y * bm;
                         w = rw[r] * fabs(j11 * j22 - j12 * j21);
                     } else {
                         const int t = p / C::NT;                   // fan triangle (p_t, p_{t+1}, bar)  quadratures.hpp:390-396
@@ -786,13 +794,15 @@ __global__ __launch_bounds__(64, PA_WAVES_PER_EU) void hho_local_ops_kernel(Loca
 #pragma unroll
                         for (int J = I; J < NTL; ++J, ++t) {
                             const int colj = 16 * J + jj;
+                            if (colj < MS) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = 16 * I + kk + 4 * r;
-                                if (row < MS && colj < MS) {
-                                    const double v = acc[t][r];
-                                    Og[row + colj * MS] = v;
-                                    if (I != J) Og[colj + row * MS] = v;
+                                for (int r = 0; r < 4; ++r) {
+                                    const int row = 16 * I + kk + 4 * r;
+                                    if (16 * I + 4 * r < MS && row < MS) {
+                                        const double v = acc[t][r];
+                                        Og[row + colj * MS] = v;
+                                        if (I != J) Og[colj + row * MS] = v;
+                                    }
                                 }
                             }
                         }
