@@ -45,6 +45,13 @@ class MeshParams(C.Structure):
 
 SCALAR_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_void_p)
 
+CUT_NEG, CUT_POS, CUT_ON_INTERFACE = 0, 1, 2
+
+
+class CutLevelSet(C.Structure):
+    _fields_ = [("kind", C.c_int), ("radius", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
+                ("cut_y", C.c_double)]
+
 
 def build():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
@@ -55,8 +62,8 @@ def lib():
     if _LIB is not None:
         return _LIB
     path = os.path.join(ORACLE_DIR, "libhho_oracle.so")
-    src = os.path.join(ORACLE_DIR, "hho_oracle.c")
-    if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+    srcs = [os.path.join(ORACLE_DIR, n) for n in ("hho_oracle.c", "hho_oracle.h", "cuthho_oracle.c", "cuthho_oracle.h")]
+    if not os.path.exists(path) or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
         build()
     L = C.CDLL(path)
     dp = C.POINTER(C.c_double)
@@ -122,6 +129,36 @@ def lib():
                                               i32p, i32p, dp, C.POINTER(C.c_size_t), i64p, dp]
     L.hho_builtin_fn.restype = SCALAR_FN
     L.hho_builtin_fn.argtypes = [C.c_int]
+    # ---- cuthho_oracle.h
+    lsp = C.POINTER(CutLevelSet)
+    L.cut_ls_eval.restype = C.c_double
+    L.cut_ls_eval.argtypes = [lsp, C.c_double, C.c_double]
+    L.cut_mesh_create.restype = C.c_void_p
+    L.cut_mesh_create.argtypes = [C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.cut_mesh_free.argtypes = [C.c_void_p]
+    L.cut_mesh_free.restype = None
+    L.cut_mesh_preprocess.argtypes = [C.c_void_p, lsp, C.c_int]
+    for name in ("cut_mesh_num_points", "cut_mesh_num_cells", "cut_mesh_num_faces", "cut_mesh_interface_points"):
+        getattr(L, name).restype = C.c_size_t
+        getattr(L, name).argtypes = [C.c_void_p]
+    for name, rt in (("cut_mesh_points", dp), ("cut_mesh_cell_ptids", u64p), ("cut_mesh_faces", u64p),
+                     ("cut_mesh_face_boundary", u8p), ("cut_mesh_node_location", C.POINTER(C.c_int8)),
+                     ("cut_mesh_face_location", C.POINTER(C.c_int8)), ("cut_mesh_face_intersection", dp),
+                     ("cut_mesh_cell_location", C.POINTER(C.c_int8))):
+        getattr(L, name).restype = rt
+        getattr(L, name).argtypes = [C.c_void_p]
+    L.cut_mesh_cell_interface.restype = dp
+    L.cut_mesh_cell_interface.argtypes = [C.c_void_p, C.c_size_t]
+    L.cut_mesh_cell_face.restype = C.c_size_t
+    L.cut_mesh_cell_face.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    L.cut_cell_quadrature.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, dp, dp, dp, C.c_int]
+    L.cut_face_quadrature.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, dp, dp, dp, C.c_int]
+    L.cut_interface_quadrature.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, dp, dp, dp, C.c_int]
+    L.cut_cell_measure.restype = C.c_double
+    L.cut_cell_measure.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    L.cut_make_hho_laplacian.argtypes = [C.c_void_p, lsp, C.c_size_t, Degrees, C.c_int, dp, dp, C.POINTER(C.c_int)]
+    L.cut_make_hho_cut_stabilization.argtypes = [C.c_void_p, C.c_size_t, Degrees, C.c_int, dp]
+    L.cut_make_rhs.argtypes = [C.c_void_p, lsp, C.c_size_t, C.c_int, C.c_int, SCALAR_FN, SCALAR_FN, C.c_void_p, dp]
     _LIB = L
     return L
 
@@ -308,3 +345,81 @@ class Assembler:
         assert st == 0
         n = nt.value
         return tr[:n], tc[:n], tv[:n], rr, rv
+
+
+class CutMesh:
+    """cuthho_poly_mesh + the preprocessing of cuthho_square.cpp:2036-2052 (oracle side)."""
+
+    def __init__(self, N, radius=0.35, center=(0.5, 0.5), refsteps=4):
+        L = lib()
+        self.L = L
+        self.N = N
+        self.ls = CutLevelSet(0, radius, center[0], center[1], 0.0)
+        self.h = L.cut_mesh_create(N, N, 0.0, 1.0, 0.0, 1.0)
+        st = L.cut_mesh_preprocess(self.h, C.byref(self.ls), refsteps)
+        if st != 0:
+            raise RuntimeError("cut_mesh_preprocess failed: %d" % st)
+        self.np_, self.nc, self.nf = (L.cut_mesh_num_points(self.h), L.cut_mesh_num_cells(self.h), L.cut_mesh_num_faces(self.h))
+        as_np = np.ctypeslib.as_array
+        self.points = as_np(L.cut_mesh_points(self.h), shape=(self.np_, 2)).copy()
+        self.ptids = as_np(L.cut_mesh_cell_ptids(self.h), shape=(self.nc, 4)).copy()
+        self.faces = as_np(L.cut_mesh_faces(self.h), shape=(self.nf, 2)).copy()
+        self.bnd = as_np(L.cut_mesh_face_boundary(self.h), shape=(self.nf,)).copy()
+        self.node_loc = as_np(L.cut_mesh_node_location(self.h), shape=(self.np_,)).copy()
+        self.face_loc = as_np(L.cut_mesh_face_location(self.h), shape=(self.nf,)).copy()
+        self.face_ip = as_np(L.cut_mesh_face_intersection(self.h), shape=(self.nf, 2)).copy()
+        self.cell_loc = as_np(L.cut_mesh_cell_location(self.h), shape=(self.nc,)).copy()
+        self.niface = L.cut_mesh_interface_points(self.h)
+        self.cell_faces = np.array([[L.cut_mesh_cell_face(self.h, c, lf) for lf in range(4)] for c in range(self.nc)],
+                                   dtype=np.uint64)
+
+    def __del__(self):
+        try:
+            self.L.cut_mesh_free(self.h)
+        except Exception:
+            pass
+
+    def interface(self, c):
+        p = self.L.cut_mesh_cell_interface(self.h, c)
+        return np.ctypeslib.as_array(p, shape=(self.niface, 2)).copy() if p else None
+
+    def cell_quadrature(self, c, degree, where=CUT_NEG):
+        qx, qy, qw = np.zeros(1024), np.zeros(1024), np.zeros(1024)
+        n = self.L.cut_cell_quadrature(self.h, c, degree, where, _dp(qx), _dp(qy), _dp(qw), 1024)
+        assert n >= 0, n
+        return qx[:n], qy[:n], qw[:n]
+
+    def face_quadrature(self, c, lf, degree, where=CUT_NEG):
+        qx, qy, qw = np.zeros(8), np.zeros(8), np.zeros(8)
+        n = self.L.cut_face_quadrature(self.h, c, lf, degree, where, _dp(qx), _dp(qy), _dp(qw), 8)
+        assert n >= 0, n
+        return qx[:n], qy[:n], qw[:n]
+
+    def interface_quadrature(self, c, degree, where=CUT_NEG):
+        qx, qy, qw = np.zeros(1024), np.zeros(1024), np.zeros(1024)
+        n = self.L.cut_interface_quadrature(self.h, c, degree, where, _dp(qx), _dp(qy), _dp(qw), 1024)
+        assert n >= 0, n
+        return qx[:n], qy[:n], qw[:n]
+
+    def laplacian(self, c, di, where=CUT_NEG):
+        ms, rbs = di.msize, di.rbs
+        oper = np.zeros((ms, rbs))
+        data = np.zeros((ms, ms))
+        rows = C.c_int(0)
+        st = self.L.cut_make_hho_laplacian(self.h, C.byref(self.ls), c, di, where, _dp(oper), _dp(data), C.byref(rows))
+        r = rows.value
+        op = np.ascontiguousarray(oper.reshape(-1)[: ms * r].reshape(ms, r).T)
+        return st, op, data.T.copy()
+
+    def cut_stabilization(self, c, di, where=CUT_NEG):
+        ms = di.msize
+        stab = np.zeros((ms, ms))
+        st = self.L.cut_make_hho_cut_stabilization(self.h, c, di, where, _dp(stab))
+        return st, stab.T.copy()
+
+    def rhs(self, c, degree, where=CUT_NEG, f_id=1, bcs_id=2):
+        cbs = (degree + 2) * (degree + 1) // 2
+        out = np.zeros(cbs)
+        st = self.L.cut_make_rhs(self.h, C.byref(self.ls), c, degree, where, self.L.hho_builtin_fn(f_id),
+                                 self.L.hho_builtin_fn(bcs_id), None, _dp(out))
+        return st, out

@@ -1,0 +1,72 @@
+"""PIN of the cutHHO part of the oracle against the reference's committed numbers:
+apps/cuthho/cuthho.xlsx sheet 1, "F.D." table (rows = interface refinement steps r, columns =
+N = 10, 20, 40; energy-norm error printed by cuthho_square.cpp:1066).  Exercises the whole chain
+of `cuthho_square -k K -M N -N N -r R -f`: level-set tagging, bisection zero crossings, node
+displacement, interface refinement, cut quadrature (fan triangulation + Dunavant with the
+rules[deg] off-by-one), cut Nitsche operators, cut stabilization, cut rhs, the generic assembler,
+and must reproduce the 6 printed digits."""
+import math
+
+import numpy as np
+import pytest
+
+import cuthho_driver as cd
+
+# cuthho.xlsx B7:D7, G7:I7, L7:N7 (r = 4) and row 8 (r = 5)
+FD = {
+    (0, 4): {10: 0.188501, 20: 9.66971e-2, 40: 4.84833e-2},
+    (1, 4): {10: 1.1089e-2, 20: 3.08508e-3, 40: 7.58577e-4},
+    (2, 4): {10: 7.28887e-4, 20: 9.30124e-5, 40: 1.17375e-5},
+    (0, 5): {10: 0.188507, 20: 9.67103e-2},
+    (1, 5): {10: 1.1089e-2, 20: 3.08498e-3},
+    (2, 5): {10: 7.28742e-4, 20: 9.29638e-5},
+}
+
+
+@pytest.mark.parametrize("k,r,N", [(k, r, N) for (k, r), d in FD.items() for N in d if N <= 20] + [(1, 4, 40), (2, 4, 40)])
+def test_fictitious_domain_energy_error_matches_xlsx(k, r, N):
+    err, msh = cd.run_fictdom(N, k, r)
+    ref = FD[(k, r)][N]
+    assert abs(err - ref) / ref < 6e-6, (err, ref)          # 6 printed digits
+
+
+def test_cut_geometry_integrates_the_disc(oracle):
+    """cuthho_square.cpp:681-732 (test_integration_domain): area and perimeter of the circle."""
+    m = oracle.CutMesh(20, refsteps=4)
+    area = per = 0.0
+    ncut = 0
+    for c in range(m.nc):
+        if m.cell_loc[c] != oracle.CUT_POS:
+            area += m.cell_quadrature(c, 2)[2].sum()
+        if m.cell_loc[c] == oracle.CUT_ON_INTERFACE:
+            ncut += 1
+            per += m.interface_quadrature(c, 2)[2].sum()
+            assert abs(m.cell_quadrature(c, 2)[2].sum() - oracle.lib().cut_cell_measure(m.h, c, oracle.CUT_NEG)) < 1e-15
+    assert ncut > 0 and (m.cell_loc == oracle.CUT_NEG).sum() > 0
+    assert abs(area - math.pi * 0.35 ** 2) < 2e-5 and abs(per - 2 * math.pi * 0.35) < 2e-5
+    # every cut cell is crossed by exactly two cut faces; its interface polyline has 2^r + 1 points on the circle
+    for c in np.nonzero(m.cell_loc == oracle.CUT_ON_INTERFACE)[0]:
+        cut_faces = [f for f in m.cell_faces[c] if m.face_loc[int(f)] == oracle.CUT_ON_INTERFACE]
+        assert len(cut_faces) == 2
+        ifc = m.interface(int(c))
+        assert ifc.shape == (17, 2)
+        rad = np.hypot(ifc[:, 0] - 0.5, ifc[:, 1] - 0.5)
+        assert np.abs(rad - 0.35).max() < 1e-4 * 0.1
+
+
+def test_cut_operator_shapes_and_symmetry(oracle):
+    m = oracle.CutMesh(10, refsteps=4)
+    di = oracle.degrees(2, 1)
+    cut = int(np.nonzero(m.cell_loc == oracle.CUT_ON_INTERFACE)[0][0])
+    reg = int(np.nonzero(m.cell_loc == oracle.CUT_NEG)[0][0])
+    st, oper, data = m.laplacian(cut, di)
+    assert st == 0 and oper.shape == (di.rbs, di.msize)                     # cut cells keep the constant mode
+    st, oper_r, data_r = m.laplacian(reg, di)
+    assert st == 0 and oper_r.shape == (di.rbs - 1, di.msize)
+    assert np.allclose(data, data.T, atol=1e-12 * np.abs(data).max())
+    st, stab = m.cut_stabilization(cut, di)
+    assert st == 0 and np.allclose(stab, stab.T, atol=1e-12 * np.abs(stab).max())
+    # a cell in the positive side gets a zero right-hand side (cuthho_square.cpp:659-664)
+    pos = int(np.nonzero(m.cell_loc == oracle.CUT_POS)[0][0])
+    st, f = m.rhs(pos, di.cell_deg)
+    assert st == 0 and np.all(f == 0.0)
