@@ -183,6 +183,37 @@ int pa_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n
                       int32_t *d_rows, int32_t *d_cols, double *d_vals,
                       int32_t *d_rhs_rows, double *d_rhs_vals);
 
+/* ---- cutHHO (fictitious domain, `cuthho_square -f`) -----------------------------------------
+ * circle_level_set / line_level_set, apps/cuthho/cuthho_square.cpp:56-124 */
+typedef struct { int32_t kind; double radius, alpha, beta, cut_y; } pa_level_set;   /* kind 0 circle, 1 line */
+enum { PA_LOC_NEGATIVE = 0, PA_LOC_POSITIVE = 1, PA_LOC_ON_INTERFACE = 2 };          /* element_location */
+
+/* Builds the generator mesh (cuthho_poly_mesh, basic_mesh.hpp:321-403) and runs the host
+ * preprocessing of cuthho_square.cpp:2036-2052 with node displacement (-D, the default):
+ * detect_node_position, detect_cut_faces, move_nodes, detect_cut_faces, detect_cut_cells,
+ * refine_interface(refsteps).  The displaced points become the context's mesh.  Errors the
+ * reference throws ("invalid number of cuts in cell", "concave poly", "interface not found in
+ * search range") are returned as PA_ERR_INVALID_ARG with the text in pa_last_error(). */
+int pa_cut_preprocess(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
+                      const pa_level_set *ls, int refsteps);
+/* cell tags (element_location per cell) and, for cut cells, their index in the cut-cell batch
+ * (-1 otherwise).  Host arrays of ncells entries; either may be NULL.  *ncut may be NULL. */
+int pa_cut_query(pa_context *ctx, size_t *ncut, int8_t *cell_location, int32_t *cut_index);
+/* The cut cells' local operators (cuthho_square.cpp:308-388, 566-621, 623-666) with
+ * hho_degree_info(face_deg + 1, face_deg) (cuthho_square.cpp:871), batched over the ncut cut
+ * cells in ascending cell order: d_oper ncut x rbs x msize (cut cells keep the constant mode:
+ * rbs rows), d_data/d_stab/d_lc ncut x msize^2, d_rhs ncut x cbs, d_info ncut.  Any may be NULL.
+ * `where` = PA_LOC_NEGATIVE or PA_LOC_POSITIVE; rhs_fn / bcs_fn = PA_FN_* built-ins. */
+int pa_cut_local_ops_batch(pa_context *ctx, int face_deg, const pa_level_set *ls, int where, int rhs_fn, int bcs_fn,
+                           double *d_oper, double *d_data, double *d_stab, double *d_lc, double *d_rhs,
+                           int32_t *d_info);
+/* Merge for the assembly loop of cuthho_square.cpp:883-900: rows of the cut cells in the
+ * cell-major d_lc / d_rhs (all cells, from pa_local_ops_batch(PA_QUAD_FAN, PA_STAB_NAIVE) and
+ * pa_cell_rhs_batch) are replaced by the cut operators; the right-hand side of uncut cells
+ * outside `where` is zeroed (cuthho_square.cpp:659-664). */
+int pa_cut_merge(pa_context *ctx, int face_deg, int where, const double *d_cut_lc, const double *d_cut_rhs,
+                 double *d_lc, double *d_rhs);
+
 /* occupancy / launch facts of the dominant kernel for the roofline bookkeeping */
 typedef struct {
     int32_t lanes_per_cell, cells_per_block, block_threads, lds_bytes_per_block;

@@ -125,6 +125,42 @@ class BatchAssembler:
                           vals.data_ptr(), rhs_rows.data_ptr(), rhs_vals.data_ptr())
         return rows, cols, vals, rhs_rows, rhs_vals
 
+    # ---- cutHHO fictitious domain (cuthho_square -f) ------------------------------------
+    def cut_preprocess(self, N, radius=0.35, center=(0.5, 0.5), refsteps=4):
+        """cuthho_square.cpp:2026-2052: mesh, circle level set, default (-D) preprocessing."""
+        self.level_set = capi.LevelSet(0, radius, center[0], center[1], 0.0)
+        self.ctx.cut_preprocess(N, N, self.level_set, refsteps)
+        self.ncut, self.cell_loc, self.cut_index = self.ctx.cut_query()
+        return self.ncut
+
+    def cut_local_ops(self, fd, where=capi.LOC_NEGATIVE, rhs_fn=capi.FN_SIN_SIN_RHS, bcs_fn=capi.FN_SIN_SIN_SOL,
+                      want=("oper", "data", "stab", "lc", "rhs", "info")):
+        cbs = (fd + 3) * (fd + 2) // 2
+        ms = cbs + 4 * (fd + 1)
+        n = self.ncut
+        shapes = {"oper": (n, ms, cbs), "data": (n, ms, ms), "stab": (n, ms, ms), "lc": (n, ms, ms), "rhs": (n, cbs)}
+        out = {}
+        for k in want:
+            out[k] = torch.empty(n, dtype=torch.int32, device=self.device) if k == "info" else \
+                torch.empty(shapes[k], dtype=torch.float64, device=self.device)
+        self.ctx.cut_local_ops(fd, self.level_set, where, rhs_fn, bcs_fn, _ptr(out.get("oper")), _ptr(out.get("data")),
+                               _ptr(out.get("stab")), _ptr(out.get("lc")), _ptr(out.get("rhs")), _ptr(out.get("info")))
+        return out
+
+    def fictdom_local_ops(self, fd, where=capi.LOC_NEGATIVE, rhs_fn=capi.FN_SIN_SIN_RHS, bcs_fn=capi.FN_SIN_SIN_SOL):
+        """The whole loop body of cuthho_square.cpp:883-900 for every cell: uncut cells through the
+        fan-quadrature / naive-stabilization kernel, cut cells through the cut kernel, merged.
+        -> (lc [n, ms, ms], rhs [n, cbs]) device tensors."""
+        cd = fd + 1
+        out = self.local_ops(cd, fd, capi.QUAD_FAN, capi.STAB_NAIVE, want=("lc",))
+        rhs = self.cell_rhs(cd, rhs_fn, capi.QUAD_FAN)
+        if self.ncut:
+            cut = self.cut_local_ops(fd, where, rhs_fn, bcs_fn, want=("lc", "rhs"))
+            self.ctx.cut_merge(fd, where, cut["lc"].data_ptr(), cut["rhs"].data_ptr(), out["lc"].data_ptr(), rhs.data_ptr())
+        else:
+            self.ctx.cut_merge(fd, where, None, None, None, rhs.data_ptr())
+        return out["lc"], rhs
+
     def synchronize(self):
         self.ctx.synchronize()
 

@@ -26,6 +26,7 @@ EXPORTS = [
     "pa_static_condensation_batch", "pa_local_ops_launch_info",
     "pa_mesh_set_faces", "pa_assembler_query", "pa_dirichlet_data_batch", "pa_face_quadrature_points",
     "pa_triplets_batch",
+    "pa_cut_preprocess", "pa_cut_query", "pa_cut_local_ops_batch", "pa_cut_merge",
 ]
 
 
@@ -46,6 +47,14 @@ class LaunchInfo(C.Structure):
 class AssemblerInfo(C.Structure):
     _fields_ = [("system_size", C.c_uint64), ("ncells_global", C.c_uint64), ("cell_base", C.c_uint64),
                 ("nfaces_local", C.c_uint64), ("face_base", C.c_uint64), ("num_other_faces", C.c_uint64)]
+
+
+class LevelSet(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("radius", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
+                ("cut_y", C.c_double)]
+
+
+LOC_NEGATIVE, LOC_POSITIVE, LOC_ON_INTERFACE = 0, 1, 2
 
 
 class ProtonAmdError(RuntimeError):
@@ -104,6 +113,10 @@ def lib():
     L.pa_dirichlet_data_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.pa_face_quadrature_points.argtypes = [vp, C.c_int, dp]
     L.pa_triplets_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp, dp, dp, dp, dp, dp]
+    L.pa_cut_preprocess.argtypes = [vp, sz, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(LevelSet), C.c_int]
+    L.pa_cut_query.argtypes = [vp, C.POINTER(sz), vp, vp]
+    L.pa_cut_local_ops_batch.argtypes = [vp, C.c_int, C.POINTER(LevelSet), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp]
+    L.pa_cut_merge.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp]
     _lib = L
     return L
 
@@ -212,6 +225,25 @@ class Context:
     def triplets(self, di, first, n, lc, rhs, g, rows, cols, vals, rhs_rows, rhs_vals):
         self._ck(self._L.pa_triplets_batch(self.h, di, first, n, lc, rhs, g, rows, cols, vals, rhs_rows, rhs_vals),
                  "pa_triplets_batch")
+
+    def cut_preprocess(self, Nx, Ny, ls, refsteps, lo=(0.0, 0.0), hi=(1.0, 1.0)):
+        self._ck(self._L.pa_cut_preprocess(self.h, Nx, Ny, lo[0], hi[0], lo[1], hi[1], C.byref(ls), refsteps), "pa_cut_preprocess")
+
+    def cut_query(self):
+        import numpy as np
+        n = C.c_size_t(0)
+        nc = self.mesh_counts()[1]
+        loc = np.zeros(nc, dtype=np.int8)
+        idx = np.zeros(nc, dtype=np.int32)
+        self._ck(self._L.pa_cut_query(self.h, C.byref(n), loc.ctypes.data, idx.ctypes.data), "pa_cut_query")
+        return n.value, loc, idx
+
+    def cut_local_ops(self, face_deg, ls, where, rhs_fn, bcs_fn, oper=None, data=None, stab=None, lc=None, rhs=None, info=None):
+        self._ck(self._L.pa_cut_local_ops_batch(self.h, face_deg, C.byref(ls), where, rhs_fn, bcs_fn, oper, data, stab, lc, rhs, info),
+                 "pa_cut_local_ops_batch")
+
+    def cut_merge(self, face_deg, where, cut_lc, cut_rhs, lc, rhs):
+        self._ck(self._L.pa_cut_merge(self.h, face_deg, where, cut_lc, cut_rhs, lc, rhs), "pa_cut_merge")
 
     def launch_info(self, di, quad, stab, n):
         li = LaunchInfo()

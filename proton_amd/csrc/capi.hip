@@ -9,6 +9,8 @@
 #include <string>
 
 #include "../../include/proton_amd.h"
+#include "cut_device.hpp"
+#include "cut_host.hpp"
 #include "hho_assembly.hpp"
 #include "hho_aux.hpp"
 #include "hho_launch.hpp"
@@ -67,6 +69,11 @@ struct pa_context {
     uint8_t *d_face_dir = nullptr;
     int32_t *d_face_compress = nullptr;
     size_t nfaces_local = 0, face_base = 0, num_other_faces = 0, ncells_global = 0, cell_base = 0;
+    // cutHHO state (host tags + device copies)
+    pa::CutMeshHost *cut = nullptr;
+    uint32_t *d_cut_cells = nullptr;
+    int8_t *d_cell_loc = nullptr;
+    int32_t *d_cut_index = nullptr;
     std::string last_error;
 };
 
@@ -89,14 +96,32 @@ static void release_faces(pa_context *ctx)
     ctx->nfaces_local = ctx->face_base = ctx->num_other_faces = 0;
 }
 
+static void release_cut(pa_context *ctx)
+{
+    delete ctx->cut; ctx->cut = nullptr;
+    if (ctx->d_cut_cells) (void)hipFree(ctx->d_cut_cells);
+    if (ctx->d_cell_loc) (void)hipFree(ctx->d_cell_loc);
+    if (ctx->d_cut_index) (void)hipFree(ctx->d_cut_index);
+    ctx->d_cut_cells = nullptr; ctx->d_cell_loc = nullptr; ctx->d_cut_index = nullptr;
+}
+
 static void release_mesh(pa_context *ctx)
 {
+    release_cut(ctx);
     release_faces(ctx);
     if (ctx->owns_mesh) {
         if (ctx->d_points) (void)hipFree(ctx->d_points);
         if (ctx->d_ptids) (void)hipFree(ctx->d_ptids);
     }
     ctx->d_points = nullptr; ctx->d_ptids = nullptr; ctx->npoints = ctx->ncells = 0; ctx->owns_mesh = false;
+}
+
+template <typename T>
+static hipError_t upload_vec(const std::vector<T> &v, T **d, hipStream_t s)
+{
+    hipError_t e = hipMalloc((void **)d, (v.size() ? v.size() : 1) * sizeof(T));
+    if (e == hipSuccess && !v.empty()) e = hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    return e;
 }
 
 extern "C" {
@@ -582,6 +607,118 @@ int pa_static_condensation_batch(pa_context *ctx, pa_degree_info di, size_t n, c
     PA_SC_CASE(2, 2) PA_SC_CASE(1, 2) PA_SC_CASE(4, 3) PA_SC_CASE(3, 3) PA_SC_CASE(2, 3)
 #undef PA_SC_CASE
     return PA_ERR_INVALID_DEGREE;
+}
+
+// ---- cutHHO -----------------------------------------------------------------------------------
+int pa_cut_preprocess(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
+                      const pa_level_set *ls, int refsteps)
+{
+    if (!ctx || !ls || refsteps < 0 || refsteps > 10 || (ls->kind != 0 && ls->kind != 1)) return PA_ERR_INVALID_ARG;
+    int st = pa_mesh_generate(ctx, Nx, Ny, min_x, max_x, min_y, max_y, 0, Ny);
+    if (st != PA_OK) return st;
+    pa::CutMeshHost *cm = new (std::nothrow) pa::CutMeshHost();
+    if (!cm) return PA_ERR_INVALID_ARG;
+    const pa::LevelSet L = {ls->kind, ls->radius, ls->alpha, ls->beta, ls->cut_y};
+    try {
+        pa::cut_preprocess(*cm, (uint32_t)Nx, (uint32_t)Ny, min_x, max_x, min_y, max_y, L, refsteps);
+    } catch (const std::exception &e) {
+        ctx->last_error = std::string("cutHHO preprocessing: ") + e.what();
+        delete cm;
+        return PA_ERR_INVALID_ARG;
+    }
+    release_cut(ctx);
+    ctx->cut = cm;
+    const size_t nc = cm->ncells(), ncut = cm->cut_cells.size();
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_points, cm->pts.data(), cm->pts.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_cut_cells, (ncut ? ncut : 1) * sizeof(uint32_t)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_cell_loc, nc));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_cut_index, nc * sizeof(int32_t)));
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_cut_cells, cm->cut_cells.data(), ncut * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_cell_loc, cm->cell_loc.data(), nc, hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_cut_index, cm->cut_index.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PA_OK;
+}
+
+int pa_cut_query(pa_context *ctx, size_t *ncut, int8_t *cell_location, int32_t *cut_index)
+{
+    if (!ctx) return PA_ERR_INVALID_ARG;
+    if (!ctx->cut) return PA_ERR_NO_MESH;
+    if (ncut) *ncut = ctx->cut->cut_cells.size();
+    if (cell_location) std::memcpy(cell_location, ctx->cut->cell_loc.data(), ctx->cut->ncells());
+    if (cut_index) std::memcpy(cut_index, ctx->cut->cut_index.data(), ctx->cut->ncells() * sizeof(int32_t));
+    return PA_OK;
+}
+
+int pa_cut_local_ops_batch(pa_context *ctx, int face_deg, const pa_level_set *ls, int where, int rhs_fn, int bcs_fn,
+                           double *d_oper, double *d_data, double *d_stab, double *d_lc, double *d_rhs, int32_t *d_info)
+{
+    if (!ctx || !ls || (where != PA_LOC_NEGATIVE && where != PA_LOC_POSITIVE)) return PA_ERR_INVALID_ARG;
+    if (!ctx->cut) return PA_ERR_NO_MESH;
+    if (face_deg < 0) return PA_ERR_INVALID_DEGREE;
+    if (face_deg > 2) return PA_ERR_QUADRATURE;            // 2*recdeg = 8 selects the empty rules[8]
+    if (rhs_fn <= PA_FN_SAMPLED || rhs_fn > PA_FN_ONE || bcs_fn <= PA_FN_SAMPLED || bcs_fn > PA_FN_ONE) return PA_ERR_INVALID_ARG;
+    const size_t ncut = ctx->cut->cut_cells.size();
+    if (ncut == 0) return PA_OK;
+    pa::CutLists L;
+    try {
+        pa::build_cut_lists(*ctx->cut, ctx->host_tab, face_deg, where, L);
+    } catch (const std::invalid_argument &e) {
+        ctx->last_error = e.what();
+        return PA_ERR_QUADRATURE;
+    } catch (const std::exception &e) {
+        ctx->last_error = e.what();
+        return PA_ERR_INVALID_ARG;
+    }
+    uint32_t *d_co = nullptr, *d_io = nullptr, *d_ro = nullptr;
+    double *d_cx = nullptr, *d_ix = nullptr, *d_rx = nullptr, *d_fl = nullptr, *d_fs = nullptr;
+    int32_t *d_flc = nullptr, *d_fsc = nullptr;
+    hipError_t e = upload_vec(L.cell_off, &d_co, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.il_off, &d_io, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.ir_off, &d_ro, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.cell_xyw, &d_cx, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.il_xyw, &d_ix, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.ir_xyw, &d_rx, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.fl_xyw, &d_fl, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.fs_xyw, &d_fs, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.fl_cnt, &d_flc, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.fs_cnt, &d_fsc, ctx->stream);
+    if (e == hipSuccess) {
+        pa::CutArgs a;
+        a.tab = ctx->d_tab; a.points = ctx->d_points; a.ptids = ctx->d_ptids; a.cut_cells = ctx->d_cut_cells;
+        a.ncut = (uint32_t)ncut;
+        a.cell_off = d_co; a.il_off = d_io; a.ir_off = d_ro;
+        a.cell_xyw = d_cx; a.il_xyw = d_ix; a.ir_xyw = d_rx; a.fl_xyw = d_fl; a.fs_xyw = d_fs; a.fl_cnt = d_flc; a.fs_cnt = d_fsc;
+        a.ls = pa::LevelSet{ls->kind, ls->radius, ls->alpha, ls->beta, ls->cut_y};
+        a.rhs_fn = rhs_fn; a.bcs_fn = bcs_fn; a.eta = 5.0;                       // cell_eta, cuthho_square.cpp:301-306
+        a.oper = d_oper; a.data = d_data; a.stab = d_stab; a.lc = d_lc; a.rhs = d_rhs; a.info = d_info;
+        const int grid = (int)(ncut < (size_t)ctx->num_cus * 4 ? ncut : (size_t)ctx->num_cus * 4);
+        switch (face_deg) {
+        case 0: hipLaunchKernelGGL((pa::cut_local_ops_kernel<0>), dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        case 1: hipLaunchKernelGGL((pa::cut_local_ops_kernel<1>), dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        default: hipLaunchKernelGGL((pa::cut_local_ops_kernel<2>), dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        }
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);               // the lists are freed below
+    }
+    (void)hipFree(d_co); (void)hipFree(d_io); (void)hipFree(d_ro); (void)hipFree(d_cx); (void)hipFree(d_ix);
+    (void)hipFree(d_rx); (void)hipFree(d_fl); (void)hipFree(d_fs); (void)hipFree(d_flc); (void)hipFree(d_fsc);
+    if (e != hipSuccess) { ctx->last_error = std::string("pa_cut_local_ops_batch: ") + hipGetErrorString(e); return PA_ERR_HIP; }
+    return PA_OK;
+}
+
+int pa_cut_merge(pa_context *ctx, int face_deg, int where, const double *d_cut_lc, const double *d_cut_rhs, double *d_lc,
+                 double *d_rhs)
+{
+    if (!ctx || face_deg < 0 || face_deg > 2 || (where != PA_LOC_NEGATIVE && where != PA_LOC_POSITIVE)) return PA_ERR_INVALID_ARG;
+    if (!ctx->cut) return PA_ERR_NO_MESH;
+    const int cbs = pa::P2(face_deg + 1), ms = cbs + 4 * (face_deg + 1);
+    const uint32_t nc = (uint32_t)ctx->cut->ncells();
+    const int grid = (int)(nc < (uint32_t)ctx->num_cus * 16 ? nc : (uint32_t)ctx->num_cus * 16);
+    hipLaunchKernelGGL(pa::cut_merge_kernel, dim3(grid), dim3(64), 0, ctx->stream, nc, ctx->d_cell_loc, ctx->d_cut_index, where,
+                       ms * ms, cbs, d_cut_lc, d_cut_rhs, d_lc, d_rhs);
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,380 @@
+// cut_device.hpp -- the cut-cell local operators of the fictitious-domain driver:
+//   make_hho_laplacian(msh, cl, level_set, di, where)   apps/cuthho/cuthho_square.cpp:308-388
+//   make_hho_cut_stabilization                          apps/cuthho/cuthho_square.cpp:566-621
+//   make_rhs(msh, cl, degree, f, where, level_set, bcs) apps/cuthho/cuthho_square.cpp:623-666
+// for the cells cut by the interface (about 0.5 % of a 512 x 512 mesh).  One wavefront per cut
+// cell; the quadrature lists come from the host preprocessing (cut_host.hpp).  The uncut cells
+// of the same mesh go through hho_local_ops_kernel (fan quadrature, naive stabilization).
+// Assumes celdeg == recdeg == facdeg + 1, as the reference's cut operators do (:381, :871).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cut_host.hpp"
+#include "hho_aux.hpp"
+#include "hho_device.hpp"
+
+namespace pa {
+
+struct CutArgs {
+    const QuadTables *tab;
+    const double *points;
+    const uint32_t *ptids;
+    const uint32_t *cut_cells;
+    uint32_t ncut;
+    const uint32_t *cell_off, *il_off, *ir_off;
+    const double *cell_xyw, *il_xyw, *ir_xyw, *fl_xyw, *fs_xyw;
+    const int32_t *fl_cnt, *fs_cnt;
+    LevelSet ls;
+    int rhs_fn, bcs_fn;
+    double eta;                     // cell_eta, cuthho_square.cpp:301-306
+    double *oper, *data, *stab, *lc, *rhs;
+    int32_t *info;
+};
+
+__device__ __forceinline__ double ipow(double x, int n)
+{
+    double v = 1.0;
+    for (int e = 0; e < n; ++e) v *= x;
+    return v;
+}
+
+template <int FD>
+__global__ __launch_bounds__(64) void cut_local_ops_kernel(CutArgs a)
+{
+    constexpr int RD = FD + 1, RBS = P2(RD), CBS = RBS, FBS = FD + 1, NF = 4 * FBS, MS = CBS + NF;
+    constexpr int NMOM = P2(2 * RD), LD = (RBS + 1) & ~1, NFPT = 4 * FACE_SLOTS, CH = 64;
+    constexpr int EPL = cdiv(MS * MS, 64);
+    // LDS map (doubles)
+    constexpr int oMOM = 0, oST = (oMOM + NMOM + 1) & ~1, oLL = oST + LD * RBS, oGR = oLL + LD * RBS, oOP = oGR + RBS * MS;
+    constexpr int oTPHI = oOP + RBS * MS, oTDN = oTPHI + CH * RBS, oTW = oTDN + CH * RBS;
+    constexpr int oFB = oTW + CH, oMF = oFB + NFPT * FBS, oTR = oMF + 4 * FBS * FBS, oPT = oTR + NF * CBS, oEND = oPT + NF * CBS;
+    __shared__ __attribute__((aligned(16))) double S[oEND];
+    const int l = threadIdx.x;
+
+    for (uint32_t cc = blockIdx.x; cc < a.ncut; cc += gridDim.x) {
+        const uint32_t cell = a.cut_cells[cc];
+        // ---- geometry of the WHOLE cell (cell_basis, normals, measure: bases.hpp:85-91,
+        // basic_geom.hpp:349-372, cuthho_square.cpp:344)
+        const uint4 idv = *reinterpret_cast<const uint4 *>(a.ptids + 4 * (size_t)cell);
+        const uint32_t ids[4] = {idv.x, idv.y, idv.z, idv.w};
+        double px[4], py[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double2 p = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)ids[v]);
+            px[v] = p.x; py[v] = p.y;
+        }
+        double barx, bary;
+        {
+            double rx = 0.0, ry = 0.0, den = 0.0;
+#pragma unroll
+            for (int i = 2; i < 4; ++i) {
+                const double ax = px[i - 1] - px[0], ay = py[i - 1] - py[0], bx = px[i] - px[0], by = py[i] - py[0];
+                const double d = (ax * by - ay * bx) / 2.0;
+                rx += (ax + bx) * d; ry += (ay + by) * d; den += d;
+            }
+            barx = px[0] + rx / (den * 3); bary = py[0] + ry / (den * 3);
+        }
+        double hd = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 4; ++j) hd = fmax(hd, sqrt((px[j] - px[i]) * (px[j] - px[i]) + (py[j] - py[i]) * (py[j] - py[i])));
+        const double ihalf = 1.0 / (0.5 * hd), ih = 2.0 / hd;
+        double hT = 0.0;
+#pragma unroll
+        for (int i = 1; i < 3; ++i)
+            hT += fabs((px[i] - px[0]) * (py[i + 1] - py[0]) - (py[i] - py[0]) * (px[i + 1] - px[0])) * 0.5;
+        const double eta_h = a.eta / hT;
+
+        // basis helpers (scaled monomials, bases.hpp:93-184), runtime index m -> exponents
+        auto phi_m = [&](double bx, double by, int m) {
+            int p, r; mono_exps(m, p, r);
+            return ipow(bx, p) * ipow(by, r);
+        };
+        auto grad_m = [&](double bx, double by, int m, double &gx, double &gy) {
+            int p, r; mono_exps(m, p, r);
+            gx = p == 0 ? 0.0 : p * ih * ipow(bx, p - 1) * ipow(by, r);
+            gy = r == 0 ? 0.0 : r * ih * ipow(bx, p) * ipow(by, r - 1);
+        };
+
+        // ---- A: cell moments over the cut quadrature, stiffness from them (cuthho_square.cpp:336-341)
+        const uint32_t c0 = a.cell_off[cc], c1 = a.cell_off[cc + 1];
+        for (int mu = l; mu < NMOM; mu += 64) {
+            int p, r; mono_exps(mu, p, r);
+            double s = 0.0;
+            for (uint32_t q = c0; q < c1; ++q) {
+                const double bx = (a.cell_xyw[3 * q] - barx) * ihalf, by = (a.cell_xyw[3 * q + 1] - bary) * ihalf;
+                s += a.cell_xyw[3 * q + 2] * ipow(bx, p) * ipow(by, r);
+            }
+            S[oMOM + mu] = s;
+        }
+        __syncthreads();
+        for (int e = l; e < RBS * RBS; e += 64) {
+            int ai, bi, aj, bj;
+            mono_exps(e % RBS, ai, bi);
+            mono_exps(e / RBS, aj, bj);
+            double v = 0.0;
+            if (ai * aj) v += (double)(ai * aj) * S[oMOM + mono_index(ai + aj - 2, bi + bj)];
+            if (bi * bj) v += (double)(bi * bj) * S[oMOM + mono_index(ai + aj, bi + bj - 2)];
+            S[oST + (e % RBS) + (e / RBS) * LD] = ih * ih * v;
+        }
+        __syncthreads();
+
+        // ---- B: Nitsche terms on the interface (cuthho_square.cpp:347-360), chunks of 64 points
+        const uint32_t i0 = a.il_off[cc], i1 = a.il_off[cc + 1];
+        for (uint32_t base = i0; base < i1; base += CH) {
+            const uint32_t q = base + l;
+            if (q < i1) {
+                const double x = a.il_xyw[3 * q], y = a.il_xyw[3 * q + 1];
+                const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
+                double nx, ny;
+                a.ls.normal(x, y, nx, ny);                    // not flipped for the positive side (:352-355)
+                for (int m = 0; m < RBS; ++m) {
+                    double gx, gy;
+                    grad_m(bx, by, m, gx, gy);
+                    S[oTPHI + l * RBS + m] = phi_m(bx, by, m);
+                    S[oTDN + l * RBS + m] = gx * nx + gy * ny;
+                }
+                S[oTW + l] = a.il_xyw[3 * q + 2];
+            } else S[oTW + l] = 0.0;
+            __syncthreads();
+            const int nq = (int)((i1 - base) < (uint32_t)CH ? (i1 - base) : (uint32_t)CH);
+            for (int e = l; e < RBS * RBS; e += 64) {
+                const int i = e % RBS, j = e / RBS;
+                double s = 0.0;
+                for (int t = 0; t < nq; ++t) {
+                    const double w = S[oTW + t], pi_ = S[oTPHI + t * RBS + i], pj = S[oTPHI + t * RBS + j];
+                    const double di_ = S[oTDN + t * RBS + i], dj = S[oTDN + t * RBS + j];
+                    s += w * (-pi_ * dj - di_ * pj + eta_h * pi_ * pj);
+                }
+                S[oST + i + j * LD] += s;
+            }
+            __syncthreads();
+        }
+
+        // ---- C: gr_lhs = stiff, gr_rhs (cuthho_square.cpp:362-383); face points of the `where` part
+        {
+            if (l < NFPT) {
+                const int f = l / FACE_SLOTS, qq = l % FACE_SLOTS;
+                const bool ok = qq < a.fl_cnt[cc * 4 + f];
+                const double *src = a.fl_xyw + (((size_t)cc * 4 + f) * FACE_SLOTS + qq) * 3;
+                const double x = ok ? src[0] : barx, y = ok ? src[1] : bary, w = ok ? src[2] : 0.0;
+                const int f1 = (f + 1) & 3;
+                const double ex = px[f1] - px[f], ey = py[f1] - py[f];          // dynamic index: 4 entries, fine here
+                const double len = sqrt(ex * ex + ey * ey);
+                const double nx = ey / len, ny = -ex / len;                      // basic_geom.hpp:361-369
+                // face basis of the WHOLE face from its lower-id endpoint (bases.hpp:253-280)
+                const bool flip = ids[f] > ids[f1];
+                const double ax = flip ? px[f1] : px[f], ay = flip ? py[f1] : py[f];
+                const double bxx = flip ? px[f] : px[f1], byy = flip ? py[f] : py[f1];
+                const double fbx = 0.5 * (ax + bxx), fby = 0.5 * (ay + byy);
+                const double ep = 4.0 * ((fbx - ax) * (x - fbx) + (fby - ay) * (y - fby)) / (len * len);
+                const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
+                for (int m = 0; m < RBS; ++m) {
+                    double gx, gy;
+                    grad_m(bx, by, m, gx, gy);
+                    S[oTPHI + l * RBS + m] = phi_m(bx, by, m);
+                    S[oTDN + l * RBS + m] = w * (gx * nx + gy * ny);
+                }
+                for (int k = 0; k < FBS; ++k) S[oFB + l * FBS + k] = ipow(ep, k);
+            }
+            __syncthreads();
+            for (int e = l; e < RBS * MS; e += 64) {
+                const int i = e % RBS, j = e / RBS;
+                double s;
+                if (j < CBS) {
+                    s = S[oST + i + j * LD];
+                    for (int p = 0; p < NFPT; ++p) s -= S[oTDN + p * RBS + i] * S[oTPHI + p * RBS + j];
+                } else {
+                    const int f = (j - CBS) / FBS, k = (j - CBS) % FBS;
+                    s = 0.0;
+                    for (int qq = 0; qq < FACE_SLOTS; ++qq) s += S[oTDN + (f * FACE_SLOTS + qq) * RBS + i] * S[oFB + (f * FACE_SLOTS + qq) * FBS + k];
+                }
+                S[oGR + i + j * RBS] = s;
+            }
+            for (int e = l; e < RBS * LD; e += 64) S[oLL + e] = S[oST + e];
+            __syncthreads();
+        }
+
+        // ---- D: oper = llt(gr_lhs).solve(gr_rhs) (cuthho_square.cpp:385), full rbs x rbs system
+        const int bad = lds_cholesky<RBS, LD, 64>(S + oLL, l);
+        {
+            double x[RBS];
+            const int c = l < MS ? l : 0;
+#pragma unroll
+            for (int k = 0; k < RBS; ++k) x[k] = S[oGR + k + c * RBS];
+            lds_forward<RBS, LD>(S + oLL, x);
+            lds_backward<RBS, LD>(S + oLL, x);
+            if (l < MS) {
+#pragma unroll
+                for (int k = 0; k < RBS; ++k) S[oOP + k + c * RBS] = x[k];
+            }
+        }
+        __syncthreads();
+        if (a.oper != nullptr)
+            for (int e = l; e < RBS * MS; e += 64) a.oper[(size_t)cc * (RBS * MS) + e] = S[oOP + e];
+
+        // ---- E: data = gr_rhs^T oper (cuthho_square.cpp:386)
+        double acc_d[EPL], acc_s[EPL];
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const int e = l + 64 * t, i = e < MS * MS ? e % MS : 0, j = e < MS * MS ? e / MS : 0;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < RBS; ++k) s += S[oGR + k + i * RBS] * S[oOP + k + j * RBS];
+            acc_d[t] = s; acc_s[t] = 0.0;
+        }
+        __syncthreads();
+
+        // ---- F: cut stabilization (cuthho_square.cpp:566-621): faces without points are skipped
+        {
+            if (l < NFPT) {
+                const int f = l / FACE_SLOTS, qq = l % FACE_SLOTS;
+                const bool ok = qq < a.fs_cnt[cc * 4 + f];
+                const double *src = a.fs_xyw + (((size_t)cc * 4 + f) * FACE_SLOTS + qq) * 3;
+                const double x = ok ? src[0] : barx, y = ok ? src[1] : bary, w = ok ? src[2] : 0.0;
+                const int f1 = (f + 1) & 3;
+                const double ex = px[f1] - px[f], ey = py[f1] - py[f];
+                const double len2 = ex * ex + ey * ey;
+                const bool flip = ids[f] > ids[f1];
+                const double ax = flip ? px[f1] : px[f], ay = flip ? py[f1] : py[f];
+                const double bxx = flip ? px[f] : px[f1], byy = flip ? py[f] : py[f1];
+                const double fbx = 0.5 * (ax + bxx), fby = 0.5 * (ay + byy);
+                const double ep = 4.0 * ((fbx - ax) * (x - fbx) + (fby - ay) * (y - fby)) / len2;
+                const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
+                for (int m = 0; m < CBS; ++m) S[oTPHI + l * RBS + m] = phi_m(bx, by, m);
+                for (int k = 0; k < FBS; ++k) S[oFB + l * FBS + k] = ipow(ep, k);
+                S[oTW + l] = w;
+            }
+            __syncthreads();
+            for (int e = l; e < 4 * FBS * FBS; e += 64) {              // mass_F  (:608)
+                const int f = e / (FBS * FBS), k = e % FBS, k2 = (e / FBS) % FBS;
+                double s = 0.0;
+                for (int qq = 0; qq < FACE_SLOTS; ++qq) {
+                    const int p = f * FACE_SLOTS + qq;
+                    s += (S[oTW + p] * S[oFB + p * FBS + k]) * S[oFB + p * FBS + k2];
+                }
+                S[oMF + f * FBS * FBS + k + k2 * FBS] = s;
+            }
+            for (int e = l; e < NF * CBS; e += 64) {                   // trace_F (:609)
+                const int fk = e % NF, i = e / NF, f = fk / FBS, k = fk % FBS;
+                double s = 0.0;
+                for (int qq = 0; qq < FACE_SLOTS; ++qq) {
+                    const int p = f * FACE_SLOTS + qq;
+                    s += (S[oTW + p] * S[oFB + p * FBS + k]) * S[oTPHI + p * RBS + i];
+                }
+                S[oTR + fk + i * NF] = s;
+            }
+            __syncthreads();
+            if (l < CBS) {                                             // mass.llt().solve(trace), column l (:615)
+                for (int f = 0; f < 4; ++f) {
+                    if (a.fs_cnt[cc * 4 + f] == 0) continue;
+                    double Lf[FBS][FBS], x[FBS];
+                    for (int j = 0; j < FBS; ++j) {                    // tiny Cholesky, redundantly per lane
+                        double d = S[oMF + f * FBS * FBS + j + j * FBS];
+                        for (int k = 0; k < j; ++k) d -= Lf[j][k] * Lf[j][k];
+                        Lf[j][j] = sqrt(d);
+                        for (int i = j + 1; i < FBS; ++i) {
+                            double s = S[oMF + f * FBS * FBS + i + j * FBS];
+                            for (int k = 0; k < j; ++k) s -= Lf[i][k] * Lf[j][k];
+                            Lf[i][j] = s / Lf[j][j];
+                        }
+                    }
+                    for (int i = 0; i < FBS; ++i) {
+                        double s = S[oTR + (f * FBS + i) + l * NF];
+                        for (int k = 0; k < i; ++k) s -= Lf[i][k] * x[k];
+                        x[i] = s / Lf[i][i];
+                    }
+                    for (int i = FBS - 1; i >= 0; --i) {
+                        double s = x[i];
+                        for (int k = i + 1; k < FBS; ++k) s -= Lf[k][i] * x[k];
+                        x[i] = s / Lf[i][i];
+                    }
+                    for (int i = 0; i < FBS; ++i) S[oPT + (f * FBS + i) + l * NF] = x[i];
+                }
+            }
+            __syncthreads();
+            // data += oper_F^T mass_F oper_F / hT, oper_F = [ M^-1 trace | -I_F ]  (:599,:615-617)
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) {
+                const int e = l + 64 * t;
+                if (e < MS * MS) {
+                    const int i = e % MS, j = e / MS;
+                    double s = 0.0;
+                    for (int f = 0; f < 4; ++f) {
+                        if (a.fs_cnt[cc * 4 + f] == 0) continue;
+                        for (int k = 0; k < FBS; ++k) {
+                            const double oi = i < CBS ? S[oPT + (f * FBS + k) + i * NF] : (i == CBS + f * FBS + k ? -1.0 : 0.0);
+                            if (oi == 0.0) continue;
+                            double mo = 0.0;
+                            for (int k2 = 0; k2 < FBS; ++k2) {
+                                const double oj = j < CBS ? S[oPT + (f * FBS + k2) + j * NF] : (j == CBS + f * FBS + k2 ? -1.0 : 0.0);
+                                mo += S[oMF + f * FBS * FBS + k + k2 * FBS] * oj;
+                            }
+                            s += oi * mo;
+                        }
+                    }
+                    acc_s[t] = s * (1.0 / hT);
+                }
+            }
+        }
+
+        // ---- G: outputs
+        {
+            const size_t off = (size_t)cc * (MS * MS);
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) {
+                const int e = l + 64 * t;
+                if (e < MS * MS) {
+                    if (a.lc != nullptr) a.lc[off + e] = acc_d[t] + acc_s[t];
+                    if (a.data != nullptr) a.data[off + e] = acc_d[t];
+                    if (a.stab != nullptr) a.stab[off + e] = acc_s[t];
+                }
+            }
+            if (a.info != nullptr && l == 0) a.info[cc] = bad;
+        }
+
+        // ---- H: right-hand side (cuthho_square.cpp:630-657)
+        if (a.rhs != nullptr && l < CBS) {
+            double s = 0.0;
+            for (uint32_t q = c0; q < c1; ++q) {                      // integrate(msh, cl, 2*degree, where): same list (degree == recdeg)
+                const double x = a.cell_xyw[3 * q], y = a.cell_xyw[3 * q + 1];
+                const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
+                s += (a.cell_xyw[3 * q + 2] * phi_m(bx, by, l)) * builtin_fn(a.rhs_fn, x, y);
+            }
+            for (uint32_t q = a.ir_off[cc]; q < a.ir_off[cc + 1]; ++q) {   // integrate_interface(msh, cl, degree, where)  (:647)
+                const double x = a.ir_xyw[3 * q], y = a.ir_xyw[3 * q + 1];
+                const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
+                double nx, ny, gx, gy;
+                a.ls.normal(x, y, nx, ny);
+                grad_m(bx, by, l, gx, gy);
+                s += (a.ir_xyw[3 * q + 2] * builtin_fn(a.bcs_fn, x, y)) * (phi_m(bx, by, l) * eta_h - (gx * nx + gy * ny));
+            }
+            a.rhs[(size_t)cc * CBS + l] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// fictitious-domain merge: the cut cells' operators replace the rows of the cell-major arrays and
+// the right-hand side of cells outside `where` is zeroed (cuthho_square.cpp:628-629, 659-664)
+__global__ void cut_merge_kernel(uint32_t ncells, const int8_t *cell_loc, const int32_t *cut_index, int where, int msize2, int cbs,
+                                 const double *cut_lc, const double *cut_rhs, double *lc, double *rhs)
+{
+    for (size_t c = blockIdx.x; c < ncells; c += gridDim.x) {
+        const int loc = cell_loc[c];
+        if (loc == LOC_CUT) {
+            const size_t cc = (size_t)cut_index[c];
+            if (lc != nullptr && cut_lc != nullptr)
+                for (int e = threadIdx.x; e < msize2; e += blockDim.x) lc[c * msize2 + e] = cut_lc[cc * msize2 + e];
+            if (rhs != nullptr && cut_rhs != nullptr)
+                for (int e = threadIdx.x; e < cbs; e += blockDim.x) rhs[c * cbs + e] = cut_rhs[cc * cbs + e];
+        } else if (loc != where && rhs != nullptr) {
+            for (int e = threadIdx.x; e < cbs; e += blockDim.x) rhs[c * cbs + e] = 0.0;
+        }
+    }
+}
+
+}  // namespace pa
