@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void cut_local_ops_kernel(CutArgs a)
         }
 
         // ---- D: oper = llt(gr_lhs).solve(gr_rhs) (cuthho_square.cpp:385), full rbs x rbs system
-        const int bad = lds_cholesky<RBS, LD, 64>(S + oLL, l);
+        const int bad = lds_cholesky<RBS, LD, 64, 2>(S + oLL, l);     // sliver cuts are badly conditioned: full-accuracy pivots
         {
             double x[RBS];
             const int c = l < MS ? l : 0;

@@ -231,7 +231,7 @@ __device__ __forceinline__ double lds_dotadd(double s, const double *p, const do
 // so every later use of a row is a run of ds_read_b128); the diagonal receives 1/L[j][j].
 // Returns 0 or 1+index of the first non-positive pivot (uniform over the G-lane group).
 // -------------------------------------------------------------------------------------
-template <int N, int LD, int G>
+template <int N, int LD, int G, int RSQ_ITERS = 1>
 __device__ __forceinline__ int lds_cholesky(double *A, int l)
 {
     double row[N];
@@ -250,7 +250,7 @@ __device__ __forceinline__ int lds_cholesky(double *A, int l)
         const double s = j == 0 ? row[0] : lds_dotsub_n(row[j], A + j * LD, row, j);
         const double d = __shfl(s, j, G);
         if (!(d > 0.0) && !bad) bad = j + 1;
-        const double r = fast_rsqrt<1>(d);      // seed 2^-26 -> ~3e-16 after one Newton step
+        const double r = fast_rsqrt<RSQ_ITERS>(d);   // seed 2^-26 -> ~3e-16 after one Newton step
         row[j] = s * r;
         if (act && l >= j) A[i * LD + j] = (l == j) ? r : row[j];
         __syncthreads();

