@@ -40,6 +40,9 @@ WORKLOADS = {
                            note="configs[3]: apps/obstacle 512x512 k=1, hho_degree_info(0,1)"),
     "quad2048_k3": dict(N=2048, cd=4, fd=3, quad="tensor", stab="fancy", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0,
                         note="configs[4]: 2048x2048 k=3 Laplacian, hho_degree_info(4,3)"),
+    "cuthho512_k2": dict(N=512, cd=3, fd=2, quad="fan", stab="naive", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0, cut=True,
+                         note="configs[2]: cuthho_square -M 512 -N 512 -k 2 -f, circle r=0.35, -r 4, node displacement: "
+                              "uncut cells (fan quadrature, naive stabilization) + cut cells (Nitsche operators), merged"),
     "quad1024_k1": dict(N=1024, cd=2, fd=1, quad="tensor", stab="fancy", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0,
                         note="1024x1024 k=1"),
     "quad1024_k3": dict(N=1024, cd=4, fd=3, quad="tensor", stab="fancy", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0,
@@ -53,6 +56,23 @@ def bytes_per_cell(msize, cbs):
     """Algorithmic bytes per cell, mode L (BASELINE.md section 4 / SURVEY.md section 8d):
     lc written (8 msize^2) + cell rhs written (8 cbs) + 4 node coordinates (64) + 4 u32 ids (16)."""
     return 8 * msize * msize + 8 * cbs + 80
+
+
+def cpu_baseline_cut(w, target_seconds=15.0):
+    """Oracle on a bounded sample of the cut workload: a smaller mesh of the same problem
+    (the per-cell cost does not depend on N; the cut-cell fraction scales like 1/N)."""
+    import oracle_lib
+    import cuthho_driver
+    N = 96
+    msh = oracle_lib.CutMesh(N, refsteps=4)
+    di = oracle_lib.degrees(w["cd"], w["fd"])
+    t0 = time.perf_counter()
+    cuthho_driver.oracle_cut_provider(msh, di)
+    dt = time.perf_counter() - t0
+    ncut = int((msh.cell_loc == oracle_lib.CUT_ON_INTERFACE).sum())
+    return {"value": msh.nc / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "%dx%d mesh of the same problem (%d cells, %d cut), %.1f s, oracle cut + uncut operators and rhs, single thread"
+                      % (N, N, msh.nc, ncut, dt)}
 
 
 def cpu_baseline(w, sample_rows, target_seconds=15.0):
@@ -124,7 +144,13 @@ def main():
     sz = pa.sizes_for(di, quad)
     asm = BatchAssembler(local_rank)
     r0, r1 = row_partition(N, world, rank)
-    asm.generate_mesh(N, N, w["lo"], w["hi"], rows=(r0, r1))
+    cut = bool(w.get("cut"))
+    if cut:
+        if world > 1:
+            raise SystemExit("the cut workload is single-GPU in this round")
+        asm.cut_preprocess(N, refsteps=4)                    # host preprocessing: outside the timed region
+    else:
+        asm.generate_mesh(N, N, w["lo"], w["hi"], rows=(r0, r1))
     n_local = asm.ncells
     dev = asm.device
 
@@ -137,6 +163,10 @@ def main():
         ex = CondensedExchange(cell_counts(N, N, world), condensed_per_cell(sz.fbs), rank, dev)
         S_view, g_view = ex.local_S_g(nf)
 
+    if cut:
+        cut_lc = torch.empty((max(asm.ncut, 1), sz.msize, sz.msize), dtype=torch.float64, device=dev)
+        cut_rhs = torch.empty((max(asm.ncut, 1), sz.cbs), dtype=torch.float64, device=dev)
+
     k_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     k_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
@@ -147,6 +177,10 @@ def main():
         if i is not None:
             k_stop[i].record()
         asm.cell_rhs(w["cd"], w["fn"], quad, dinc=w["dinc"], out=rhs)
+        if cut and asm.ncut:
+            asm.ctx.cut_local_ops(w["fd"], asm.level_set, pa.capi.LOC_NEGATIVE, w["fn"], 2, None, None, None,
+                                  cut_lc.data_ptr(), cut_rhs.data_ptr(), None)
+            asm.ctx.cut_merge(w["fd"], pa.capi.LOC_NEGATIVE, cut_lc.data_ptr(), cut_rhs.data_ptr(), lc.data_ptr(), rhs.data_ptr())
         if exchange:
             asm.ctx.static_condensation(di, n_local, lc.data_ptr(), rhs.data_ptr(), S_view.data_ptr(), g_view.data_ptr(),
                                         None, None)
@@ -215,7 +249,7 @@ def main():
             "kernel_only_cells_per_s": total_cells / (kern_ms * 1e-3) if world == 1 else n_local * world / (kern_ms * 1e-3),
         }
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(w, args.cpu_sample_rows)
+            res["cpu_baseline"] = cpu_baseline_cut(w) if cut else cpu_baseline(w, args.cpu_sample_rows)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
         else:
             res["cpu_baseline"] = None

@@ -39,10 +39,9 @@ def configs():
 
 
 def _deps_mtime():
-    names = ["hho_device.hpp", "hho_launch.hpp", "hho_aux.hpp", "quad_tables.hpp", "pa_configs.def",
-             "hho_inst.hip", "capi.hip", os.path.join("..", "..", "include", "proton_amd.h"),
-             os.path.join("..", "_build.py")]
-    return max(os.path.getmtime(os.path.join(CSRC, n)) for n in names)
+    deps = [os.path.join(CSRC, n) for n in os.listdir(CSRC)]
+    deps += [os.path.join(HERE, "..", "include", "proton_amd.h"), os.path.join(HERE, "_build.py")]
+    return max(os.path.getmtime(d) for d in deps)
 
 
 def _compile(job):

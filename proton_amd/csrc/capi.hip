@@ -71,6 +71,13 @@ struct pa_context {
     size_t nfaces_local = 0, face_base = 0, num_other_faces = 0, ncells_global = 0, cell_base = 0;
     // cutHHO state (host tags + device copies)
     pa::CutMeshHost *cut = nullptr;
+    // device copies of the cut quadrature lists, built once per (face degree, side)
+    struct CutListsDev {
+        int face_deg = -1, where = -1;
+        uint32_t *co = nullptr, *io = nullptr, *ro = nullptr;
+        double *cx = nullptr, *ix = nullptr, *rx = nullptr, *fl = nullptr, *fs = nullptr;
+        int32_t *flc = nullptr, *fsc = nullptr;
+    } cl;
     uint32_t *d_cut_cells = nullptr;
     int8_t *d_cell_loc = nullptr;
     int32_t *d_cut_index = nullptr;
@@ -96,8 +103,17 @@ static void release_faces(pa_context *ctx)
     ctx->nfaces_local = ctx->face_base = ctx->num_other_faces = 0;
 }
 
+static void release_cut_lists(pa_context *ctx)
+{
+    auto &c = ctx->cl;
+    (void)hipFree(c.co); (void)hipFree(c.io); (void)hipFree(c.ro); (void)hipFree(c.cx); (void)hipFree(c.ix);
+    (void)hipFree(c.rx); (void)hipFree(c.fl); (void)hipFree(c.fs); (void)hipFree(c.flc); (void)hipFree(c.fsc);
+    c = pa_context::CutListsDev();
+}
+
 static void release_cut(pa_context *ctx)
 {
+    release_cut_lists(ctx);
     delete ctx->cut; ctx->cut = nullptr;
     if (ctx->d_cut_cells) (void)hipFree(ctx->d_cut_cells);
     if (ctx->d_cell_loc) (void)hipFree(ctx->d_cell_loc);
@@ -660,35 +676,40 @@ int pa_cut_local_ops_batch(pa_context *ctx, int face_deg, const pa_level_set *ls
     if (rhs_fn <= PA_FN_SAMPLED || rhs_fn > PA_FN_ONE || bcs_fn <= PA_FN_SAMPLED || bcs_fn > PA_FN_ONE) return PA_ERR_INVALID_ARG;
     const size_t ncut = ctx->cut->cut_cells.size();
     if (ncut == 0) return PA_OK;
-    pa::CutLists L;
-    try {
-        pa::build_cut_lists(*ctx->cut, ctx->host_tab, face_deg, where, L);
-    } catch (const std::invalid_argument &e) {
-        ctx->last_error = e.what();
-        return PA_ERR_QUADRATURE;
-    } catch (const std::exception &e) {
-        ctx->last_error = e.what();
-        return PA_ERR_INVALID_ARG;
+    hipError_t e = hipSuccess;
+    if (ctx->cl.face_deg != face_deg || ctx->cl.where != where) {     // host list building + upload: once
+        pa::CutLists L;
+        try {
+            pa::build_cut_lists(*ctx->cut, ctx->host_tab, face_deg, where, L);
+        } catch (const std::invalid_argument &ex) {
+            ctx->last_error = ex.what();
+            return PA_ERR_QUADRATURE;
+        } catch (const std::exception &ex) {
+            ctx->last_error = ex.what();
+            return PA_ERR_INVALID_ARG;
+        }
+        release_cut_lists(ctx);
+        auto &c = ctx->cl;
+        e = upload_vec(L.cell_off, &c.co, ctx->stream);
+        if (e == hipSuccess) e = upload_vec(L.il_off, &c.io, ctx->stream);
+        if (e == hipSuccess) e = upload_vec(L.ir_off, &c.ro, ctx->stream);
+        if (e == hipSuccess) e = upload_vec(L.cell_xyw, &c.cx, ctx->stream);
+        if (e == hipSuccess) e = upload_vec(L.il_xyw, &c.ix, ctx->stream);
+        if (e == hipSuccess) e = upload_vec(L.ir_xyw, &c.rx, ctx->stream);
+        if (e == hipSuccess) e = upload_vec(L.fl_xyw, &c.fl, ctx->stream);
+        if (e == hipSuccess) e = upload_vec(L.fs_xyw, &c.fs, ctx->stream);
+        if (e == hipSuccess) e = upload_vec(L.fl_cnt, &c.flc, ctx->stream);
+        if (e == hipSuccess) e = upload_vec(L.fs_cnt, &c.fsc, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // the host vectors go out of scope
+        if (e == hipSuccess) { c.face_deg = face_deg; c.where = where; }
     }
-    uint32_t *d_co = nullptr, *d_io = nullptr, *d_ro = nullptr;
-    double *d_cx = nullptr, *d_ix = nullptr, *d_rx = nullptr, *d_fl = nullptr, *d_fs = nullptr;
-    int32_t *d_flc = nullptr, *d_fsc = nullptr;
-    hipError_t e = upload_vec(L.cell_off, &d_co, ctx->stream);
-    if (e == hipSuccess) e = upload_vec(L.il_off, &d_io, ctx->stream);
-    if (e == hipSuccess) e = upload_vec(L.ir_off, &d_ro, ctx->stream);
-    if (e == hipSuccess) e = upload_vec(L.cell_xyw, &d_cx, ctx->stream);
-    if (e == hipSuccess) e = upload_vec(L.il_xyw, &d_ix, ctx->stream);
-    if (e == hipSuccess) e = upload_vec(L.ir_xyw, &d_rx, ctx->stream);
-    if (e == hipSuccess) e = upload_vec(L.fl_xyw, &d_fl, ctx->stream);
-    if (e == hipSuccess) e = upload_vec(L.fs_xyw, &d_fs, ctx->stream);
-    if (e == hipSuccess) e = upload_vec(L.fl_cnt, &d_flc, ctx->stream);
-    if (e == hipSuccess) e = upload_vec(L.fs_cnt, &d_fsc, ctx->stream);
     if (e == hipSuccess) {
+        const auto &c = ctx->cl;
         pa::CutArgs a;
         a.tab = ctx->d_tab; a.points = ctx->d_points; a.ptids = ctx->d_ptids; a.cut_cells = ctx->d_cut_cells;
         a.ncut = (uint32_t)ncut;
-        a.cell_off = d_co; a.il_off = d_io; a.ir_off = d_ro;
-        a.cell_xyw = d_cx; a.il_xyw = d_ix; a.ir_xyw = d_rx; a.fl_xyw = d_fl; a.fs_xyw = d_fs; a.fl_cnt = d_flc; a.fs_cnt = d_fsc;
+        a.cell_off = c.co; a.il_off = c.io; a.ir_off = c.ro;
+        a.cell_xyw = c.cx; a.il_xyw = c.ix; a.ir_xyw = c.rx; a.fl_xyw = c.fl; a.fs_xyw = c.fs; a.fl_cnt = c.flc; a.fs_cnt = c.fsc;
         a.ls = pa::LevelSet{ls->kind, ls->radius, ls->alpha, ls->beta, ls->cut_y};
         a.rhs_fn = rhs_fn; a.bcs_fn = bcs_fn; a.eta = 5.0;                       // cell_eta, cuthho_square.cpp:301-306
         a.oper = d_oper; a.data = d_data; a.stab = d_stab; a.lc = d_lc; a.rhs = d_rhs; a.info = d_info;
@@ -699,10 +720,7 @@ int pa_cut_local_ops_batch(pa_context *ctx, int face_deg, const pa_level_set *ls
         default: hipLaunchKernelGGL((pa::cut_local_ops_kernel<2>), dim3(grid), dim3(64), 0, ctx->stream, a); break;
         }
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);               // the lists are freed below
     }
-    (void)hipFree(d_co); (void)hipFree(d_io); (void)hipFree(d_ro); (void)hipFree(d_cx); (void)hipFree(d_ix);
-    (void)hipFree(d_rx); (void)hipFree(d_fl); (void)hipFree(d_fs); (void)hipFree(d_flc); (void)hipFree(d_fsc);
     if (e != hipSuccess) { ctx->last_error = std::string("pa_cut_local_ops_batch: ") + hipGetErrorString(e); return PA_ERR_HIP; }
     return PA_OK;
 }

@@ -41,15 +41,16 @@ __device__ __forceinline__ double ipow(double x, int n)
 }
 
 template <int FD>
-__global__ __launch_bounds__(64) void cut_local_ops_kernel(CutArgs a)
+__global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
 {
     constexpr int RD = FD + 1, RBS = P2(RD), CBS = RBS, FBS = FD + 1, NF = 4 * FBS, MS = CBS + NF;
     constexpr int NMOM = P2(2 * RD), LD = (RBS + 1) & ~1, NFPT = 4 * FACE_SLOTS, CH = 64;
-    constexpr int EPL = cdiv(MS * MS, 64);
     // LDS map (doubles)
     constexpr int oMOM = 0, oST = (oMOM + NMOM + 1) & ~1, oLL = oST + LD * RBS, oGR = oLL + LD * RBS, oOP = oGR + RBS * MS;
-    constexpr int oTPHI = oOP + RBS * MS, oTDN = oTPHI + CH * RBS, oTW = oTDN + CH * RBS;
-    constexpr int oFB = oTW + CH, oMF = oFB + NFPT * FBS, oTR = oMF + 4 * FBS * FBS, oPT = oTR + NF * CBS, oEND = oPT + NF * CBS;
+    constexpr int PW = 2 * (2 * RD + 1) + 1;                   // per-point scratch row: w bx^e, by^e, f
+    constexpr int ROWW = imax(2 * RBS, PW);
+    constexpr int oTPHI = oOP + RBS * MS, oTDN = oTPHI + CH * RBS, oTW = oTPHI + CH * ROWW;
+    constexpr int oFB = oTW + CH, oMF = oFB + NFPT * FBS, oTR = oMF + 4 * FBS * FBS, oPT = oTR + NF * CBS, oDATA = oPT + NF * CBS, oEND = oDATA + MS * MS;
     __shared__ __attribute__((aligned(16))) double S[oEND];
     const int l = threadIdx.x;
 
@@ -99,17 +100,40 @@ __global__ __launch_bounds__(64) void cut_local_ops_kernel(CutArgs a)
             gy = r == 0 ? 0.0 : r * ih * ipow(bx, p) * ipow(by, r - 1);
         };
 
-        // ---- A: cell moments over the cut quadrature, stiffness from them (cuthho_square.cpp:336-341)
+        // ---- A: cell moments over the cut quadrature (cuthho_square.cpp:336-341) and, from the same
+        // points, the volume part of the right-hand side (:639-644; degree == recdeg: same list).
+        // Chunks of 64 points: one lane per point stages w*bx^e, by^e and f(x) in LDS, then one lane
+        // per moment (and one per rhs mode) accumulates.
         const uint32_t c0 = a.cell_off[cc], c1 = a.cell_off[cc + 1];
-        for (int mu = l; mu < NMOM; mu += 64) {
-            int p, r; mono_exps(mu, p, r);
-            double s = 0.0;
-            for (uint32_t q = c0; q < c1; ++q) {
-                const double bx = (a.cell_xyw[3 * q] - barx) * ihalf, by = (a.cell_xyw[3 * q + 1] - bary) * ihalf;
-                s += a.cell_xyw[3 * q + 2] * ipow(bx, p) * ipow(by, r);
+        constexpr int NPW = 2 * RD + 1;
+        double mom_acc = 0.0, rhs_acc = 0.0;
+        int mp = 0, mr = 0, rp = 0, rr = 0;
+        if (l < NMOM) mono_exps(l, mp, mr);
+        if (l < CBS) mono_exps(l, rp, rr);
+        for (uint32_t base = c0; base < c1; base += CH) {
+            const uint32_t q = base + l;
+            if (q < c1) {
+                const double x = a.cell_xyw[3 * q], y = a.cell_xyw[3 * q + 1], w = a.cell_xyw[3 * q + 2];
+                const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
+                double vx = w, vy = 1.0;
+                for (int e = 0; e < NPW; ++e) {
+                    S[oTPHI + l * ROWW + e] = vx;
+                    S[oTPHI + l * ROWW + NPW + e] = vy;
+                    vx *= bx; vy *= by;
+                }
+                S[oTPHI + l * ROWW + 2 * NPW] = a.rhs != nullptr ? builtin_fn(a.rhs_fn, x, y) : 0.0;
             }
-            S[oMOM + mu] = s;
+            __syncthreads();
+            const int nq = (int)((c1 - base) < (uint32_t)CH ? (c1 - base) : (uint32_t)CH);
+            if (l < NMOM)
+                for (int t = 0; t < nq; ++t) mom_acc += S[oTPHI + t * ROWW + mp] * S[oTPHI + t * ROWW + NPW + mr];
+            if (l < CBS)
+                for (int t = 0; t < nq; ++t)
+                    rhs_acc += (S[oTPHI + t * ROWW + rp] * S[oTPHI + t * ROWW + NPW + rr]) * S[oTPHI + t * ROWW + 2 * NPW];
+            __syncthreads();
         }
+        static_assert(NMOM <= 64, "one lane per moment");
+        if (l < NMOM) S[oMOM + l] = mom_acc;
         __syncthreads();
         for (int e = l; e < RBS * RBS; e += 64) {
             int ai, bi, aj, bj;
@@ -216,15 +240,14 @@ __global__ __launch_bounds__(64) void cut_local_ops_kernel(CutArgs a)
         if (a.oper != nullptr)
             for (int e = l; e < RBS * MS; e += 64) a.oper[(size_t)cc * (RBS * MS) + e] = S[oOP + e];
 
-        // ---- E: data = gr_rhs^T oper (cuthho_square.cpp:386)
-        double acc_d[EPL], acc_s[EPL];
-#pragma unroll
-        for (int t = 0; t < EPL; ++t) {
-            const int e = l + 64 * t, i = e < MS * MS ? e % MS : 0, j = e < MS * MS ? e / MS : 0;
+        // ---- E: data = gr_rhs^T oper (cuthho_square.cpp:386), kept in an LDS image
+#pragma unroll 1
+        for (int e = l; e < MS * MS; e += 64) {
+            const int i = e % MS, j = e / MS;
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < RBS; ++k) s += S[oGR + k + i * RBS] * S[oOP + k + j * RBS];
-            acc_d[t] = s; acc_s[t] = 0.0;
+            S[oDATA + e] = s;
         }
         __syncthreads();
 
@@ -269,6 +292,7 @@ __global__ __launch_bounds__(64) void cut_local_ops_kernel(CutArgs a)
             }
             __syncthreads();
             if (l < CBS) {                                             // mass.llt().solve(trace), column l (:615)
+#pragma unroll 1
                 for (int f = 0; f < 4; ++f) {
                     if (a.fs_cnt[cc * 4 + f] == 0) continue;
                     double Lf[FBS][FBS], x[FBS];
@@ -296,63 +320,64 @@ __global__ __launch_bounds__(64) void cut_local_ops_kernel(CutArgs a)
                 }
             }
             __syncthreads();
-            // data += oper_F^T mass_F oper_F / hT, oper_F = [ M^-1 trace | -I_F ]  (:599,:615-617)
-#pragma unroll
-            for (int t = 0; t < EPL; ++t) {
-                const int e = l + 64 * t;
-                if (e < MS * MS) {
-                    const int i = e % MS, j = e / MS;
-                    double s = 0.0;
-                    for (int f = 0; f < 4; ++f) {
-                        if (a.fs_cnt[cc * 4 + f] == 0) continue;
-                        for (int k = 0; k < FBS; ++k) {
-                            const double oi = i < CBS ? S[oPT + (f * FBS + k) + i * NF] : (i == CBS + f * FBS + k ? -1.0 : 0.0);
-                            if (oi == 0.0) continue;
-                            double mo = 0.0;
-                            for (int k2 = 0; k2 < FBS; ++k2) {
-                                const double oj = j < CBS ? S[oPT + (f * FBS + k2) + j * NF] : (j == CBS + f * FBS + k2 ? -1.0 : 0.0);
-                                mo += S[oMF + f * FBS * FBS + k + k2 * FBS] * oj;
-                            }
-                            s += oi * mo;
-                        }
-                    }
-                    acc_s[t] = s * (1.0 / hT);
-                }
-            }
-        }
-
-        // ---- G: outputs
-        {
+            // data += oper_F^T mass_F oper_F / hT, oper_F = [ M^-1 trace | -I_F ]  (:599,:615-617); outputs
             const size_t off = (size_t)cc * (MS * MS);
-#pragma unroll
-            for (int t = 0; t < EPL; ++t) {
-                const int e = l + 64 * t;
-                if (e < MS * MS) {
-                    if (a.lc != nullptr) a.lc[off + e] = acc_d[t] + acc_s[t];
-                    if (a.data != nullptr) a.data[off + e] = acc_d[t];
-                    if (a.stab != nullptr) a.stab[off + e] = acc_s[t];
+#pragma unroll 1
+            for (int e = l; e < MS * MS; e += 64) {
+                const int i = e % MS, j = e / MS;
+                double s = 0.0;
+#pragma unroll 1
+                for (int f = 0; f < 4; ++f) {
+                    if (a.fs_cnt[cc * 4 + f] == 0) continue;
+#pragma unroll 1
+                    for (int k = 0; k < FBS; ++k) {
+                        const double oi = i < CBS ? S[oPT + (f * FBS + k) + i * NF] : (i == CBS + f * FBS + k ? -1.0 : 0.0);
+                        if (oi == 0.0) continue;
+                        double mo = 0.0;
+                        for (int k2 = 0; k2 < FBS; ++k2) {
+                            const double oj = j < CBS ? S[oPT + (f * FBS + k2) + j * NF] : (j == CBS + f * FBS + k2 ? -1.0 : 0.0);
+                            mo += S[oMF + f * FBS * FBS + k + k2 * FBS] * oj;
+                        }
+                        s += oi * mo;
+                    }
                 }
+                const double st = s * (1.0 / hT), dt = S[oDATA + e];
+                if (a.lc != nullptr) a.lc[off + e] = dt + st;
+                if (a.data != nullptr) a.data[off + e] = dt;
+                if (a.stab != nullptr) a.stab[off + e] = st;
             }
             if (a.info != nullptr && l == 0) a.info[cc] = bad;
         }
 
-        // ---- H: right-hand side (cuthho_square.cpp:630-657)
-        if (a.rhs != nullptr && l < CBS) {
-            double s = 0.0;
-            for (uint32_t q = c0; q < c1; ++q) {                      // integrate(msh, cl, 2*degree, where): same list (degree == recdeg)
-                const double x = a.cell_xyw[3 * q], y = a.cell_xyw[3 * q + 1];
-                const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
-                s += (a.cell_xyw[3 * q + 2] * phi_m(bx, by, l)) * builtin_fn(a.rhs_fn, x, y);
+        // ---- H: right-hand side (cuthho_square.cpp:630-657).  The source / boundary functions are
+        // evaluated once per quadrature point (one lane each, chunks of 64), then lane i sums its mode.
+        if (a.rhs != nullptr) {
+            double s = rhs_acc;                                         // volume part, accumulated in stage A
+            const uint32_t r0 = a.ir_off[cc], r1 = a.ir_off[cc + 1];      // integrate_interface(msh, cl, degree, where)  (:647)
+            for (uint32_t base = r0; base < r1; base += CH) {
+                const uint32_t q = base + l;
+                if (q < r1) {
+                    const double x = a.ir_xyw[3 * q], y = a.ir_xyw[3 * q + 1];
+                    double nx, ny;
+                    a.ls.normal(x, y, nx, ny);
+                    S[oTPHI + 5 * l] = (x - barx) * ihalf;
+                    S[oTPHI + 5 * l + 1] = (y - bary) * ihalf;
+                    S[oTPHI + 5 * l + 2] = a.ir_xyw[3 * q + 2] * builtin_fn(a.bcs_fn, x, y);
+                    S[oTPHI + 5 * l + 3] = nx;
+                    S[oTPHI + 5 * l + 4] = ny;
+                }
+                __syncthreads();
+                const int nq = (int)((r1 - base) < (uint32_t)CH ? (r1 - base) : (uint32_t)CH);
+                if (l < CBS)
+                    for (int t = 0; t < nq; ++t) {
+                        const double bx = S[oTPHI + 5 * t], by = S[oTPHI + 5 * t + 1];
+                        double gx, gy;
+                        grad_m(bx, by, l, gx, gy);
+                        s += S[oTPHI + 5 * t + 2] * (phi_m(bx, by, l) * eta_h - (gx * S[oTPHI + 5 * t + 3] + gy * S[oTPHI + 5 * t + 4]));
+                    }
+                __syncthreads();
             }
-            for (uint32_t q = a.ir_off[cc]; q < a.ir_off[cc + 1]; ++q) {   // integrate_interface(msh, cl, degree, where)  (:647)
-                const double x = a.ir_xyw[3 * q], y = a.ir_xyw[3 * q + 1];
-                const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
-                double nx, ny, gx, gy;
-                a.ls.normal(x, y, nx, ny);
-                grad_m(bx, by, l, gx, gy);
-                s += (a.ir_xyw[3 * q + 2] * builtin_fn(a.bcs_fn, x, y)) * (phi_m(bx, by, l) * eta_h - (gx * nx + gy * ny));
-            }
-            a.rhs[(size_t)cc * CBS + l] = s;
+            if (l < CBS) a.rhs[(size_t)cc * CBS + l] = s;
         }
         __syncthreads();
     }
