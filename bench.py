@@ -63,7 +63,7 @@ def cpu_baseline_cut(w, target_seconds=15.0):
     (the per-cell cost does not depend on N; the cut-cell fraction scales like 1/N)."""
     import oracle_lib
     import cuthho_driver
-    N = 96
+    N = min(w["N"], 384)            # ~5-10 s of single-thread work
     msh = oracle_lib.CutMesh(N, refsteps=4)
     di = oracle_lib.degrees(w["cd"], w["fd"])
     t0 = time.perf_counter()
