@@ -183,6 +183,40 @@ int pa_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n
                       int32_t *d_rows, int32_t *d_cols, double *d_vals,
                       int32_t *d_rhs_rows, double *d_rhs_vals);
 
+/* assembler::take_local_data (hho.hpp:408-449) for cells [first, first+n): d_out n x msize =
+ * the cell's dofs of `d_solution` (system_size values), Dirichlet faces filled from d_g
+ * (pa_dirichlet_data_batch; NULL = homogeneous). */
+int pa_take_local_data_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n,
+                             const double *d_solution, const double *d_g, double *d_out);
+
+/* ---- obstacle_assembler<Mesh> (hho.hpp:471-751) ---------------------------------------------
+ * These entry points need the whole mesh on the context (no row slab).
+ * Constructor tables (hho.hpp:538-578): d_in_A ncells flags (is_in_set_A), d_A_ct / d_B_ct
+ * ncells int32: position among the cells outside / inside the active set, -1 otherwise.
+ * *num_I / *num_A (host) receive the two counts. */
+int pa_obstacle_tables(pa_context *ctx, const uint8_t *d_in_A, int32_t *d_A_ct, int32_t *d_B_ct,
+                       size_t *num_I, size_t *num_A);
+/* obstacle_assembler::assemble (hho.hpp:609-695) for cells [first, first+n).  Slot layout:
+ * msize^2 + 1 slots per cell, slot i*msize + j = lhs(i,j) in the reference's push order, the last
+ * slot the multiplier coupling (row cell*cbs, column num_I*cbs + num_other*fbs + B_ct[cell], 1.0)
+ * of active cells (hho.hpp:688-693); rows/cols = -1 for slots the reference does not push.
+ * Rows are not compressed (cell rows at cell + i, hho.hpp:631: exact for cbs = 1, the only case
+ * obstacle.cpp:51 uses), columns are (hho.hpp:625,645).  d_gamma: one value per cell
+ * (hho.hpp:677).  d_rhs_rows / d_rhs_vals: n x msize as in pa_triplets_batch. */
+int pa_obstacle_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n,
+                               const double *d_lc, const double *d_rhs, const double *d_g, const double *d_gamma,
+                               const uint8_t *d_in_A, const int32_t *d_A_ct, const int32_t *d_B_ct, size_t num_I,
+                               int32_t *d_rows, int32_t *d_cols, double *d_vals,
+                               int32_t *d_rhs_rows, double *d_rhs_vals);
+/* obstacle_assembler::expand_solution (hho.hpp:698-744): d_alpha ncells*cbs + nfaces*fbs (cells,
+ * then ALL faces, Dirichlet ones from d_g), d_beta ncells*cbs multipliers. */
+int pa_obstacle_expand_solution(pa_context *ctx, pa_degree_info di, const double *d_solution, const double *d_g,
+                                const double *d_gamma, const uint8_t *d_in_A, const int32_t *d_A_ct,
+                                const int32_t *d_B_ct, size_t num_I, double *d_alpha, double *d_beta);
+/* free take_local_data(msh, cl, di, expanded_solution) (hho.hpp:753-782): d_out n x msize */
+int pa_obstacle_take_local_data_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n,
+                                      const double *d_expanded, double *d_out);
+
 /* ---- cutHHO (fictitious domain, `cuthho_square -f`) -----------------------------------------
  * circle_level_set / line_level_set, apps/cuthho/cuthho_square.cpp:56-124 */
 typedef struct { int32_t kind; double radius, alpha, beta, cut_y; } pa_level_set;   /* kind 0 circle, 1 line */

@@ -933,6 +933,99 @@ int hho_assembler_assemble_cell(hho_degrees di, size_t cell_offset, size_t ncell
 }
 
 /* ------------------------------------------------------------------ */
+/* obstacle_assembler (hho.hpp:471-751)                                 */
+/* ------------------------------------------------------------------ */
+void hho_obstacle_tables(const uint8_t *in_A, size_t ncells, int64_t *A_ct, int64_t *B_ct, size_t *num_I, size_t *num_A)
+{
+    size_t ci = 0, ca = 0;
+    for (size_t i = 0; i < ncells; i++) {                              /* :538-578 */
+        if (!in_A[i]) { A_ct[i] = (int64_t)ci++; B_ct[i] = -1; }
+        else          { B_ct[i] = (int64_t)ca++; A_ct[i] = -1; }
+    }
+    *num_I = ci; *num_A = ca;
+}
+
+int hho_obstacle_assemble_cell(hho_degrees di, size_t cell_offset, size_t ncells, size_t num_I, size_t num_other_faces,
+                               const uint64_t face_ids[4], const uint8_t face_dirichlet[4], const int64_t *face_ct,
+                               const uint8_t *in_A, const int64_t *A_ct, const int64_t *B_ct,
+                               const double *lhs, const double *rhs, const double *gamma, const double *dirichlet_data,
+                               int32_t *trip_rows, int32_t *trip_cols, double *trip_vals, size_t *ntrip,
+                               int64_t *rhs_rows, double *rhs_vals)
+{
+    int cbs = hho_cell_basis_size(di.cell_deg), fbs = hho_face_basis_size(di.face_deg);
+    int msize = cbs + 4 * fbs;
+    int64_t row[HHO_MAX_MSIZE], col[HHO_MAX_MSIZE];
+    int row_ok[HHO_MAX_MSIZE], col_ok[HHO_MAX_MSIZE];
+    int active = in_A[cell_offset] != 0;
+    int64_t cell_LHS_offset = active ? 0 : A_ct[cell_offset] * cbs;   /* :625 (the value is unused when active) */
+    for (int i = 0; i < cbs; i++) {                                    /* :629-633 */
+        row[i] = (int64_t)cell_offset + i; row_ok[i] = 1;
+        col[i] = cell_LHS_offset + i;      col_ok[i] = !active;
+    }
+    for (int f = 0; f < 4; f++) {                                      /* :640-661 */
+        int dirichlet = face_dirichlet[f];
+        int64_t comp = dirichlet ? 0 : face_ct[face_ids[f]];
+        for (int i = 0; i < fbs; i++) {
+            row[cbs + f * fbs + i] = (int64_t)((size_t)cbs * ncells) + comp * fbs + i;   /* :644 */
+            col[cbs + f * fbs + i] = (int64_t)((size_t)cbs * num_I) + comp * fbs + i;    /* :645 */
+            row_ok[cbs + f * fbs + i] = col_ok[cbs + f * fbs + i] = !dirichlet;
+        }
+    }
+    size_t nt = 0;
+    for (int i = 0; i < msize; i++) { rhs_rows[i] = row_ok[i] ? row[i] : -1; rhs_vals[i] = 0.0; }
+    for (int i = 0; i < msize; i++) {                                  /* :666-682 */
+        if (!row_ok[i]) continue;
+        for (int j = 0; j < msize; j++) {
+            double v = lhs[IDX(i, j, msize)];
+            if (col_ok[j]) { trip_rows[nt] = (int32_t)row[i]; trip_cols[nt] = (int32_t)col[j]; trip_vals[nt] = v; nt++; }
+            else if (j < cbs) rhs_vals[i] -= v * gamma[cell_offset];   /* :677 */
+            else rhs_vals[i] -= v * dirichlet_data[j];                 /* :679 */
+        }
+    }
+    for (int i = 0; i < cbs; i++) rhs_vals[i] += rhs[i];              /* :686 */
+    if (active) {                                                      /* :688-693 */
+        trip_rows[nt] = (int32_t)(cell_offset * (size_t)cbs);
+        trip_cols[nt] = (int32_t)(num_I * (size_t)cbs + num_other_faces * (size_t)fbs + (size_t)B_ct[cell_offset]);
+        trip_vals[nt] = 1.0;
+        nt++;
+    }
+    *ntrip = nt;
+    return HHO_OK;
+}
+
+void hho_obstacle_expand_solution(hho_degrees di, size_t ncells, size_t nfaces, const uint8_t *face_dirichlet,
+                                  const int64_t *face_ct, const uint8_t *in_A, const double *solution,
+                                  const double *g, const double *gamma, double *alpha, double *beta)
+{
+    int cbs = hho_cell_basis_size(di.cell_deg), fbs = hho_face_basis_size(di.face_deg);
+    size_t num_I = 0, num_other = 0;
+    for (size_t i = 0; i < ncells; i++) num_I += !in_A[i];
+    for (size_t f = 0; f < nfaces; f++) num_other += !face_dirichlet[f];
+    for (size_t i = 0; i < ncells * (size_t)cbs; i++) alpha[i] = gamma[i];                    /* :709 */
+    for (size_t i = 0, co = 0; i < ncells; i++)                                               /* :710-714 */
+        if (!in_A[i]) { for (int k = 0; k < cbs; k++) alpha[i * cbs + k] = solution[co * cbs + k]; co++; }
+    for (size_t i = 0; i < ncells * (size_t)cbs; i++) beta[i] = 0.0;   /* :716 sizes beta by the CELL count: enough for cbs = 1 only */
+    for (size_t i = 0, co = 0; i < ncells; i++)                                               /* :717-721 */
+        if (in_A[i]) {
+            for (int k = 0; k < cbs; k++) beta[i * cbs + k] = solution[num_I * cbs + num_other * fbs + co * cbs + k];
+            co++;
+        }
+    for (size_t f = 0; f < nfaces; f++)                                                       /* :723-743 */
+        for (int k = 0; k < fbs; k++)
+            alpha[ncells * cbs + f * fbs + k] = face_dirichlet[f] ? g[f * fbs + k]
+                                                                  : solution[cbs * num_I + (size_t)face_ct[f] * fbs + k];
+}
+
+void hho_obstacle_take_local_data(hho_degrees di, size_t cell_offset, size_t ncells, const uint64_t face_ids[4],
+                                  const double *expanded, double *out)
+{
+    int cbs = hho_cell_basis_size(di.cell_deg), fbs = hho_face_basis_size(di.face_deg);
+    for (int i = 0; i < cbs; i++) out[i] = expanded[cell_offset * cbs + i];                   /* :764-770 */
+    for (int f = 0; f < 4; f++)                                                               /* :772-778 */
+        for (int k = 0; k < fbs; k++) out[cbs + f * fbs + k] = expanded[(size_t)cbs * ncells + face_ids[f] * fbs + k];
+}
+
+/* ------------------------------------------------------------------ */
 /* Batched loop == the reference's per-cell "Matrix assembly" span     */
 /* (convergence_test.cpp:202-213 without the triplet push).            */
 /* ------------------------------------------------------------------ */

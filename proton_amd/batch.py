@@ -125,6 +125,56 @@ class BatchAssembler:
                           vals.data_ptr(), rhs_rows.data_ptr(), rhs_vals.data_ptr())
         return rows, cols, vals, rhs_rows, rhs_vals
 
+    def take_local_data(self, cd, fd, solution, g=None, first=0, n=None):
+        """assembler::take_local_data (hho.hpp:408-449) for cells [first, first+n) -> n x msize."""
+        di, _ = capi.degree_info(cd, fd)
+        n = self.ncells - first if n is None else n
+        ms = (cd + 1) * (cd + 2) // 2 + 4 * (fd + 1)
+        out = torch.empty((n, ms), dtype=torch.float64, device=self.device)
+        self.ctx.take_local_data(di, first, n, solution.data_ptr(), _ptr(g), out.data_ptr())
+        return out
+
+    # ---- obstacle_assembler (hho.hpp:471-751) -------------------------------------------
+    def obstacle_tables(self, in_A):
+        """-> (A_ct, B_ct, num_I, num_A) for the uint8 flags in_A (hho.hpp:538-578)."""
+        A_ct = torch.empty(self.ncells, dtype=torch.int32, device=self.device)
+        B_ct = torch.empty(self.ncells, dtype=torch.int32, device=self.device)
+        num_I, num_A = self.ctx.obstacle_tables(in_A.data_ptr(), A_ct.data_ptr(), B_ct.data_ptr())
+        return A_ct, B_ct, num_I, num_A
+
+    def obstacle_triplets(self, cd, fd, lc, rhs, g, gamma, in_A, A_ct, B_ct, num_I, first=0):
+        """obstacle_assembler::assemble -> (rows, cols, vals) n x (msize^2 + 1), rhs_rows, rhs_vals n x msize."""
+        di, _ = capi.degree_info(cd, fd)
+        n, ms = lc.shape[0], lc.shape[1]
+        rows = torch.empty((n, ms * ms + 1), dtype=torch.int32, device=self.device)
+        cols = torch.empty((n, ms * ms + 1), dtype=torch.int32, device=self.device)
+        vals = torch.empty((n, ms * ms + 1), dtype=torch.float64, device=self.device)
+        rhs_rows = torch.empty((n, ms), dtype=torch.int32, device=self.device)
+        rhs_vals = torch.empty((n, ms), dtype=torch.float64, device=self.device)
+        self.ctx.obstacle_triplets(di, first, n, lc.data_ptr(), _ptr(rhs), _ptr(g), gamma.data_ptr(), in_A.data_ptr(),
+                                   A_ct.data_ptr(), B_ct.data_ptr(), num_I, rows.data_ptr(), cols.data_ptr(),
+                                   vals.data_ptr(), rhs_rows.data_ptr(), rhs_vals.data_ptr())
+        return rows, cols, vals, rhs_rows, rhs_vals
+
+    def obstacle_expand_solution(self, cd, fd, solution, g, gamma, in_A, A_ct, B_ct, num_I, nfaces):
+        """obstacle_assembler::expand_solution -> (alpha, beta)."""
+        di, _ = capi.degree_info(cd, fd)
+        cbs = (cd + 1) * (cd + 2) // 2
+        alpha = torch.empty(self.ncells * cbs + nfaces * (fd + 1), dtype=torch.float64, device=self.device)
+        beta = torch.empty(self.ncells * cbs, dtype=torch.float64, device=self.device)
+        self.ctx.obstacle_expand_solution(di, solution.data_ptr(), _ptr(g), gamma.data_ptr(), in_A.data_ptr(),
+                                          A_ct.data_ptr(), B_ct.data_ptr(), num_I, alpha.data_ptr(), beta.data_ptr())
+        return alpha, beta
+
+    def obstacle_take_local_data(self, cd, fd, expanded, first=0, n=None):
+        """free take_local_data(msh, cl, di, expanded_solution) (hho.hpp:753-782) -> n x msize."""
+        di, _ = capi.degree_info(cd, fd)
+        n = self.ncells - first if n is None else n
+        ms = (cd + 1) * (cd + 2) // 2 + 4 * (fd + 1)
+        out = torch.empty((n, ms), dtype=torch.float64, device=self.device)
+        self.ctx.obstacle_take_local_data(di, first, n, expanded.data_ptr(), out.data_ptr())
+        return out
+
     # ---- cutHHO fictitious domain (cuthho_square -f) ------------------------------------
     def cut_preprocess(self, N, radius=0.35, center=(0.5, 0.5), refsteps=4):
         """cuthho_square.cpp:2026-2052: mesh, circle level set, default (-D) preprocessing."""

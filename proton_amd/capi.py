@@ -25,7 +25,9 @@ EXPORTS = [
     "pa_local_ops_batch", "pa_cell_rhs_batch", "pa_cell_quadrature_points",
     "pa_static_condensation_batch", "pa_local_ops_launch_info",
     "pa_mesh_set_faces", "pa_assembler_query", "pa_dirichlet_data_batch", "pa_face_quadrature_points",
-    "pa_triplets_batch",
+    "pa_triplets_batch", "pa_take_local_data_batch",
+    "pa_obstacle_tables", "pa_obstacle_triplets_batch", "pa_obstacle_expand_solution",
+    "pa_obstacle_take_local_data_batch",
     "pa_cut_preprocess", "pa_cut_query", "pa_cut_local_ops_batch", "pa_cut_merge",
 ]
 
@@ -113,6 +115,11 @@ def lib():
     L.pa_dirichlet_data_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.pa_face_quadrature_points.argtypes = [vp, C.c_int, dp]
     L.pa_triplets_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp, dp, dp, dp, dp, dp]
+    L.pa_take_local_data_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp]
+    L.pa_obstacle_tables.argtypes = [vp, vp, vp, vp, C.POINTER(sz), C.POINTER(sz)]
+    L.pa_obstacle_triplets_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp, dp, vp, vp, vp, sz, dp, dp, dp, dp, dp]
+    L.pa_obstacle_expand_solution.argtypes = [vp, DegreeInfo, dp, dp, dp, vp, vp, vp, sz, dp, dp]
+    L.pa_obstacle_take_local_data_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp]
     L.pa_cut_preprocess.argtypes = [vp, sz, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(LevelSet), C.c_int]
     L.pa_cut_query.argtypes = [vp, C.POINTER(sz), vp, vp]
     L.pa_cut_local_ops_batch.argtypes = [vp, C.c_int, C.POINTER(LevelSet), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp]
@@ -225,6 +232,26 @@ class Context:
     def triplets(self, di, first, n, lc, rhs, g, rows, cols, vals, rhs_rows, rhs_vals):
         self._ck(self._L.pa_triplets_batch(self.h, di, first, n, lc, rhs, g, rows, cols, vals, rhs_rows, rhs_vals),
                  "pa_triplets_batch")
+
+    def take_local_data(self, di, first, n, solution, g, out):
+        self._ck(self._L.pa_take_local_data_batch(self.h, di, first, n, solution, g, out), "pa_take_local_data_batch")
+
+    def obstacle_tables(self, in_A, A_ct, B_ct):
+        ni, na = C.c_size_t(0), C.c_size_t(0)
+        self._ck(self._L.pa_obstacle_tables(self.h, in_A, A_ct, B_ct, C.byref(ni), C.byref(na)), "pa_obstacle_tables")
+        return ni.value, na.value
+
+    def obstacle_triplets(self, di, first, n, lc, rhs, g, gamma, in_A, A_ct, B_ct, num_I, rows, cols, vals, rhs_rows, rhs_vals):
+        self._ck(self._L.pa_obstacle_triplets_batch(self.h, di, first, n, lc, rhs, g, gamma, in_A, A_ct, B_ct, num_I,
+                                                    rows, cols, vals, rhs_rows, rhs_vals), "pa_obstacle_triplets_batch")
+
+    def obstacle_expand_solution(self, di, solution, g, gamma, in_A, A_ct, B_ct, num_I, alpha, beta):
+        self._ck(self._L.pa_obstacle_expand_solution(self.h, di, solution, g, gamma, in_A, A_ct, B_ct, num_I, alpha, beta),
+                 "pa_obstacle_expand_solution")
+
+    def obstacle_take_local_data(self, di, first, n, expanded, out):
+        self._ck(self._L.pa_obstacle_take_local_data_batch(self.h, di, first, n, expanded, out),
+                 "pa_obstacle_take_local_data_batch")
 
     def cut_preprocess(self, Nx, Ny, ls, refsteps, lo=(0.0, 0.0), hi=(1.0, 1.0)):
         self._ck(self._L.pa_cut_preprocess(self.h, Nx, Ny, lo[0], hi[0], lo[1], hi[1], C.byref(ls), refsteps), "pa_cut_preprocess")

@@ -439,6 +439,117 @@ int pa_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n
     return PA_OK;
 }
 
+static int take_local(pa_context *ctx, pa_degree_info di, size_t first, size_t n, const double *d_solution,
+                      const double *d_g, int expanded, double *d_out)
+{
+    if (!ctx || !d_solution || !d_out) return PA_ERR_INVALID_ARG;
+    if (di.cell_deg < 0 || di.face_deg < 0 || di.face_deg > 3 || di.cell_deg > 4) return PA_ERR_INVALID_DEGREE;
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
+    if (n == 0) return PA_OK;
+    pa::TakeArgs a;
+    a.cell_faces = ctx->d_cell_faces; a.face_compress = ctx->d_face_compress; a.g = d_g; a.solution = d_solution;
+    a.first = first; a.n = n; a.cell_base = ctx->cell_base; a.ncells_global = ctx->ncells_global;
+    a.face_base = ctx->face_base; a.cbs = pa::P2(di.cell_deg); a.fbs = di.face_deg + 1; a.expanded = expanded;
+    a.out = d_out;
+    const size_t total = n * (size_t)(a.cbs + 4 * a.fbs);
+    hipLaunchKernelGGL(pa::take_local_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
+int pa_take_local_data_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n, const double *d_solution,
+                             const double *d_g, double *d_out)
+{
+    return take_local(ctx, di, first, n, d_solution, d_g, 0, d_out);
+}
+
+int pa_obstacle_take_local_data_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n,
+                                      const double *d_expanded, double *d_out)
+{
+    return take_local(ctx, di, first, n, d_expanded, nullptr, 1, d_out);
+}
+
+static bool whole_mesh(const pa_context *ctx)
+{
+    return ctx->d_cell_faces && ctx->cell_base == 0 && ctx->ncells == ctx->ncells_global;
+}
+
+int pa_obstacle_tables(pa_context *ctx, const uint8_t *d_in_A, int32_t *d_A_ct, int32_t *d_B_ct, size_t *num_I,
+                       size_t *num_A)
+{
+    if (!ctx || !d_in_A || !d_A_ct || !d_B_ct) return PA_ERR_INVALID_ARG;
+    if (!ctx->d_ptids) return PA_ERR_NO_MESH;
+    const uint32_t n = (uint32_t)ctx->ncells;
+    const uint32_t nblocks = (n + pa::SCAN_TILE - 1) / pa::SCAN_TILE;
+    uint32_t *d_counts = nullptr;
+    PA_HIP(ctx, hipMalloc(&d_counts, (nblocks + 1) * sizeof(uint32_t)));
+    hipLaunchKernelGGL(pa::active_count_kernel, dim3(nblocks), dim3(pa::SCAN_BLOCK), 0, ctx->stream, d_in_A, n, d_counts);
+    hipLaunchKernelGGL(pa::active_block_scan_kernel, dim3(1), dim3(pa::SCAN_BLOCK), 0, ctx->stream, d_counts, nblocks);
+    hipLaunchKernelGGL(pa::active_tables_kernel, dim3(nblocks), dim3(pa::SCAN_BLOCK), 0, ctx->stream, d_in_A, n, d_counts,
+                       d_A_ct, d_B_ct);
+    uint32_t total = 0;
+    hipError_t e = hipMemcpyAsync(&total, d_counts + nblocks, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_counts);
+    PA_HIP(ctx, e);
+    if (num_A) *num_A = total;
+    if (num_I) *num_I = n - total;
+    return PA_OK;
+}
+
+int pa_obstacle_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n, const double *d_lc,
+                               const double *d_rhs, const double *d_g, const double *d_gamma, const uint8_t *d_in_A,
+                               const int32_t *d_A_ct, const int32_t *d_B_ct, size_t num_I, int32_t *d_rows,
+                               int32_t *d_cols, double *d_vals, int32_t *d_rhs_rows, double *d_rhs_vals)
+{
+    if (!ctx || !d_lc || !d_gamma || !d_in_A || !d_A_ct || !d_B_ct || !d_rows || !d_cols || !d_vals || !d_rhs_rows ||
+        !d_rhs_vals)
+        return PA_ERR_INVALID_ARG;
+    if (di.cell_deg < 0 || di.face_deg < 0 || di.face_deg > 3 || di.cell_deg > 4) return PA_ERR_INVALID_DEGREE;
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    if (!whole_mesh(ctx)) { ctx->last_error = "obstacle assembler needs the whole mesh on the context"; return PA_ERR_INVALID_ARG; }
+    if (first > ctx->ncells || n > ctx->ncells - first || num_I > ctx->ncells) return PA_ERR_INVALID_ARG;
+    pa_assembler_info info;
+    pa_assembler_query(ctx, di, &info);
+    if (info.system_size >= ((uint64_t)1 << 31)) return PA_ERR_INVALID_ARG;
+    if (n == 0) return PA_OK;
+    pa::ObstacleArgs o;
+    pa::TripletArgs &a = o.t;
+    a.cell_faces = ctx->d_cell_faces; a.face_dir = ctx->d_face_dir; a.face_compress = ctx->d_face_compress;
+    a.g = d_g; a.lc = d_lc; a.rhs = d_rhs; a.first = first; a.n = n;
+    a.cell_base = 0; a.ncells_global = ctx->ncells_global;
+    a.cbs = pa::P2(di.cell_deg); a.fbs = di.face_deg + 1;
+    a.rows = d_rows; a.cols = d_cols; a.vals = d_vals; a.rhs_rows = d_rhs_rows; a.rhs_vals = d_rhs_vals;
+    o.in_A = d_in_A; o.A_ct = d_A_ct; o.B_ct = d_B_ct; o.gamma = d_gamma; o.num_I = num_I; o.num_other = ctx->num_other_faces;
+    const int msize = a.cbs + 4 * a.fbs;
+    const size_t shmem = msize * sizeof(double) + 2 * msize * sizeof(int32_t);
+    const size_t resident = (size_t)ctx->num_cus * 8;
+    const int grid = (int)(n < resident ? n : resident);
+    hipLaunchKernelGGL(pa::obstacle_triplets_kernel, dim3(grid), dim3(256), shmem, ctx->stream, o);
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
+int pa_obstacle_expand_solution(pa_context *ctx, pa_degree_info di, const double *d_solution, const double *d_g,
+                                const double *d_gamma, const uint8_t *d_in_A, const int32_t *d_A_ct,
+                                const int32_t *d_B_ct, size_t num_I, double *d_alpha, double *d_beta)
+{
+    if (!ctx || !d_solution || !d_gamma || !d_in_A || !d_A_ct || !d_B_ct || !d_alpha || !d_beta) return PA_ERR_INVALID_ARG;
+    if (di.cell_deg < 0 || di.face_deg < 0 || di.face_deg > 3 || di.cell_deg > 4) return PA_ERR_INVALID_DEGREE;
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    if (!whole_mesh(ctx)) { ctx->last_error = "obstacle assembler needs the whole mesh on the context"; return PA_ERR_INVALID_ARG; }
+    pa::ExpandArgs a;
+    a.in_A = d_in_A; a.face_dir = ctx->d_face_dir; a.A_ct = d_A_ct; a.B_ct = d_B_ct; a.face_compress = ctx->d_face_compress;
+    a.solution = d_solution; a.g = d_g; a.gamma = d_gamma;
+    a.ncells = ctx->ncells; a.nfaces = ctx->nfaces_local; a.num_I = num_I; a.num_other = ctx->num_other_faces;
+    a.cbs = pa::P2(di.cell_deg); a.fbs = di.face_deg + 1; a.alpha = d_alpha; a.beta = d_beta;
+    const uint64_t total = a.ncells * a.cbs + a.nfaces * a.fbs;
+    hipLaunchKernelGGL(pa::obstacle_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
 int pa_mesh_counts(pa_context *ctx, size_t *npoints, size_t *ncells)
 {
     if (!ctx) return PA_ERR_INVALID_ARG;

@@ -225,4 +225,209 @@ __global__ __launch_bounds__(256) void triplets_kernel(TripletArgs a)
     }
 }
 
+// assembler::take_local_data (hho.hpp:408-449): one thread per (cell, local dof)
+struct TakeArgs {
+    const uint32_t *cell_faces; const int32_t *face_compress; const double *g;
+    const double *solution;        // global vector (compressed faces)   -- or the expanded one
+    size_t first, n; uint64_t cell_base, ncells_global, face_base;
+    int cbs, fbs, expanded;        // expanded: faces at cbs*ncells + face_id*fbs (hho.hpp:753-782)
+    double *out;
+};
+
+__global__ __launch_bounds__(256) void take_local_data_kernel(TakeArgs a)
+{
+    const int msize = a.cbs + 4 * a.fbs;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n * msize) return;
+    const size_t c = t / msize, cl = a.first + c;
+    const int i = (int)(t % msize);
+    double v;
+    if (i < a.cbs) {
+        v = a.solution[(a.cell_base + cl) * a.cbs + i];
+    } else {
+        const int f = (i - a.cbs) / a.fbs, k = (i - a.cbs) % a.fbs;
+        const uint32_t fl = a.cell_faces[4 * cl + f];
+        if (a.expanded) {
+            v = a.solution[a.cbs * a.ncells_global + (a.face_base + fl) * a.fbs + k];
+        } else {
+            const int32_t comp = a.face_compress[fl];
+            v = comp < 0 ? (a.g ? a.g[(size_t)fl * a.fbs + k] : 0.0)
+                         : a.solution[a.cbs * a.ncells_global + (uint64_t)comp * a.fbs + k];
+        }
+    }
+    a.out[t] = v;
+}
+
+// ---- obstacle_assembler (hho.hpp:471-751) ----------------------------------------------------
+// compress tables A_ct / B_ct (hho.hpp:538-578) = exclusive prefix counts of the cells outside /
+// inside the active set: a three-pass scan (per-block counts, scan of the block counts by one
+// block, per-block rescan with the block offset).
+constexpr int SCAN_BLOCK = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *sh, uint32_t &total)
+{
+    // wave scan with DPP-free shuffles, then a scan of the 4 wave totals through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
+        if (w < wave) base += sh[w];
+        tot += sh[w];
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void active_count_kernel(const uint8_t *in_A, uint32_t n, uint32_t *block_counts)
+{
+    __shared__ uint32_t sh[SCAN_BLOCK / 64];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) cnt += in_A[base + k] ? 1 : 0;
+    uint32_t total;
+    block_exclusive_scan(cnt, sh, total);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+
+// one block: exclusive scan of the block counts in place; the grand total goes to counts[nblocks]
+__global__ __launch_bounds__(SCAN_BLOCK) void active_block_scan_kernel(uint32_t *counts, uint32_t nblocks)
+{
+    __shared__ uint32_t sh[SCAN_BLOCK / 64];
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += SCAN_BLOCK) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = i < nblocks ? counts[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, sh, total);
+        if (i < nblocks) counts[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) counts[nblocks] = carry;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void active_tables_kernel(const uint8_t *in_A, uint32_t n, const uint32_t *block_offsets,
+                                                                   int32_t *A_ct, int32_t *B_ct)
+{
+    __shared__ uint32_t sh[SCAN_BLOCK / 64];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint8_t flag[SCAN_ITEMS];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        flag[k] = (base + k < n && in_A[base + k]) ? 1 : 0;
+        cnt += flag[k];
+    }
+    uint32_t total;
+    uint32_t active_before = block_offsets[blockIdx.x] + block_exclusive_scan(cnt, sh, total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t i = base + k;
+        if (i < n) {
+            B_ct[i] = flag[k] ? (int32_t)active_before : -1;               // hho.hpp:567-578
+            A_ct[i] = flag[k] ? -1 : (int32_t)(i - active_before);        // hho.hpp:538-549
+        }
+        active_before += flag[k];
+    }
+}
+
+struct ObstacleArgs {
+    TripletArgs t;                 // rows/cols/vals hold msize^2 + 1 slots per cell (the multiplier coupling last)
+    const uint8_t *in_A;
+    const int32_t *A_ct, *B_ct;
+    const double *gamma;           // ncells x cbs... the reference indexes gamma(cell_offset): one value per cell
+    uint64_t num_I, num_other;
+};
+
+// obstacle_assembler::assemble (hho.hpp:609-695): one block per cell, one thread per (i, j) slot.
+__global__ __launch_bounds__(256) void obstacle_triplets_kernel(ObstacleArgs o)
+{
+    extern __shared__ double sh[];                    // dirichlet data (msize), then int32 row (msize), col (msize)
+    const TripletArgs &a = o.t;
+    const int msize = a.cbs + 4 * a.fbs, slots = msize * msize + 1;
+    double *dd = sh;
+    int32_t *row = reinterpret_cast<int32_t *>(sh + msize), *col = row + msize;
+    for (size_t c = blockIdx.x; c < a.n; c += gridDim.x) {
+        const size_t cl = a.first + c;
+        const bool active = o.in_A[cl] != 0;
+        for (int i = threadIdx.x; i < msize; i += blockDim.x) {
+            int32_t r, q; double d = 0.0;
+            if (i < a.cbs) {
+                r = (int32_t)(cl + i);                                                    // hho.hpp:631 (no * cbs)
+                q = active ? -1 : (int32_t)((uint64_t)o.A_ct[cl] * a.cbs + i);            // :625,632
+            } else {
+                const int f = (i - a.cbs) / a.fbs, k = (i - a.cbs) % a.fbs;
+                const uint32_t fl = a.cell_faces[4 * cl + f];
+                const int32_t comp = a.face_compress[fl];
+                r = comp < 0 ? -1 : (int32_t)(a.cbs * a.ncells_global + (uint64_t)comp * a.fbs + k);   // :644
+                q = comp < 0 ? -1 : (int32_t)(a.cbs * o.num_I + (uint64_t)comp * a.fbs + k);           // :645
+                if (comp < 0 && a.g != nullptr) d = a.g[(size_t)fl * a.fbs + k];                       // :655-660
+            }
+            row[i] = r; col[i] = q; dd[i] = d;
+        }
+        __syncthreads();
+        const double *A = a.lc + c * (size_t)(msize * msize);
+        const double gam = o.gamma[cl];
+        for (int e = threadIdx.x; e < slots; e += blockDim.x) {
+            const size_t dst = c * (size_t)slots + e;
+            if (e == slots - 1) {                                                         // :688-693
+                a.rows[dst] = active ? (int32_t)(cl * a.cbs) : -1;
+                a.cols[dst] = active ? (int32_t)(o.num_I * a.cbs + o.num_other * a.fbs + (uint64_t)o.B_ct[cl]) : -1;
+                a.vals[dst] = 1.0;
+            } else {
+                const int i = e / msize, j = e % msize;
+                const bool keep = row[i] >= 0 && col[j] >= 0;                             // :668,673
+                a.rows[dst] = keep ? row[i] : -1;
+                a.cols[dst] = keep ? col[j] : -1;
+                a.vals[dst] = A[i + j * msize];
+            }
+        }
+        for (int i = threadIdx.x; i < msize; i += blockDim.x) {
+            double s = 0.0;
+            if (row[i] >= 0)
+                for (int j = 0; j < msize; ++j)
+                    if (col[j] < 0) s -= A[i + j * msize] * (j < a.cbs ? gam : dd[j]);    // :676-679
+            if (i < a.cbs && a.rhs != nullptr) s += a.rhs[c * a.cbs + i];                 // :686
+            a.rhs_rows[c * msize + i] = row[i];
+            a.rhs_vals[c * msize + i] = row[i] >= 0 ? s : 0.0;
+        }
+        __syncthreads();
+    }
+}
+
+// obstacle_assembler::expand_solution (hho.hpp:698-744): thread t < ncells*cbs handles a cell dof
+// of alpha and beta, the following nfaces*fbs threads the face dofs of alpha
+struct ExpandArgs {
+    const uint8_t *in_A, *face_dir; const int32_t *A_ct, *B_ct, *face_compress;
+    const double *solution, *g, *gamma;
+    uint64_t ncells, nfaces, num_I, num_other; int cbs, fbs;
+    double *alpha, *beta;
+};
+
+__global__ __launch_bounds__(256) void obstacle_expand_kernel(ExpandArgs a)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t ncd = a.ncells * a.cbs;
+    if (t < ncd) {
+        const uint64_t c = t / a.cbs; const int k = (int)(t % a.cbs);
+        const bool active = a.in_A[c] != 0;
+        a.alpha[t] = active ? a.gamma[t] : a.solution[(uint64_t)a.A_ct[c] * a.cbs + k];               // :709-714
+        a.beta[t] = active ? a.solution[a.num_I * a.cbs + a.num_other * a.fbs + (uint64_t)a.B_ct[c] * a.cbs + k] : 0.0;   // :716-721
+    } else if (t < ncd + a.nfaces * a.fbs) {
+        const uint64_t u = t - ncd, f = u / a.fbs; const int k = (int)(u % a.fbs);
+        const int32_t comp = a.face_compress[f];
+        a.alpha[t] = comp < 0 ? (a.g ? a.g[u] : 0.0) : a.solution[a.cbs * a.num_I + (uint64_t)comp * a.fbs + k];   // :723-743
+    }
+}
+
 }  // namespace pa

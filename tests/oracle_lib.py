@@ -127,6 +127,15 @@ def lib():
     L.hho_dirichlet_face_data.argtypes = [dp, dp, C.c_int, SCALAR_FN, C.c_void_p, dp]
     L.hho_assembler_assemble_cell.argtypes = [Degrees, C.c_size_t, C.c_size_t, u64p, u8p, i64p, dp, dp, dp,
                                               i32p, i32p, dp, C.POINTER(C.c_size_t), i64p, dp]
+    L.hho_obstacle_tables.restype = None
+    L.hho_obstacle_tables.argtypes = [u8p, C.c_size_t, i64p, i64p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.hho_obstacle_assemble_cell.argtypes = [Degrees, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, u64p, u8p, i64p,
+                                             u8p, i64p, i64p, dp, dp, dp, dp,
+                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, C.POINTER(C.c_size_t), i64p, dp]
+    L.hho_obstacle_expand_solution.restype = None
+    L.hho_obstacle_expand_solution.argtypes = [Degrees, C.c_size_t, C.c_size_t, u8p, i64p, u8p, dp, dp, dp, dp, dp]
+    L.hho_obstacle_take_local_data.restype = None
+    L.hho_obstacle_take_local_data.argtypes = [Degrees, C.c_size_t, C.c_size_t, u64p, dp, dp]
     L.hho_builtin_fn.restype = SCALAR_FN
     L.hho_builtin_fn.argtypes = [C.c_int]
     # ---- cuthho_oracle.h
@@ -345,6 +354,72 @@ class Assembler:
         assert st == 0
         n = nt.value
         return tr[:n], tc[:n], tv[:n], rr, rv
+
+
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _i64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+class ObstacleAssembler(Assembler):
+    """obstacle_assembler<Mesh> (hho.hpp:471-751) through the oracle's C restatement."""
+
+    def __init__(self, mp, points, ptids, di, in_A, bf_id=None):
+        super().__init__(mp, points, ptids, di, bf_id)
+        L = lib()
+        self.in_A = np.ascontiguousarray(np.asarray(in_A).astype(np.uint8))
+        assert self.in_A.shape == (self.nc,)
+        self.A_ct = np.zeros(self.nc, dtype=np.int64)
+        self.B_ct = np.zeros(self.nc, dtype=np.int64)
+        ni, na = C.c_size_t(0), C.c_size_t(0)
+        L.hho_obstacle_tables(_u8p(self.in_A), self.nc, _i64p(self.A_ct), _i64p(self.B_ct), C.byref(ni), C.byref(na))
+        self.num_I, self.num_A = ni.value, na.value
+        self.system_size = di.cbs * (self.num_I + self.num_A) + di.fbs * self.num_other      # hho.hpp:586
+
+    def assemble_cell(self, c, lhs_rowcol, rhs, gamma):
+        L = lib()
+        di = self.di
+        ms, cbs, fbs = di.msize, di.cbs, di.fbs
+        lhs = np.ascontiguousarray(lhs_rowcol.T)
+        rhs = np.ascontiguousarray(np.asarray(rhs, dtype=np.float64))
+        fids = np.ascontiguousarray(self.cell_faces[c])
+        fdir = np.ascontiguousarray(self.is_dir[fids.astype(np.int64)])
+        dd = np.zeros(ms)
+        for lf in range(4):
+            dd[cbs + lf * fbs: cbs + (lf + 1) * fbs] = self.g[int(fids[lf])]
+        tr = np.zeros(ms * ms + 1, dtype=np.int32)
+        tc = np.zeros(ms * ms + 1, dtype=np.int32)
+        tv = np.zeros(ms * ms + 1)
+        nt = C.c_size_t(0)
+        rr = np.zeros(ms, dtype=np.int64)
+        rv = np.zeros(ms)
+        st = L.hho_obstacle_assemble_cell(di, c, self.nc, self.num_I, self.num_other, _u64p(fids), _u8p(fdir),
+                                          _i64p(self.compress), _u8p(self.in_A), _i64p(self.A_ct), _i64p(self.B_ct),
+                                          _dp(lhs), _dp(rhs), _dp(gamma), _dp(dd),
+                                          tr.ctypes.data_as(C.POINTER(C.c_int32)), tc.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          _dp(tv), C.byref(nt), _i64p(rr), _dp(rv))
+        assert st == 0
+        n = nt.value
+        return tr[:n], tc[:n], tv[:n], rr, rv
+
+    def expand_solution(self, solution, gamma):
+        """-> (alpha, beta)  hho.hpp:698-744"""
+        di = self.di
+        alpha = np.zeros(self.nc * di.cbs + self.nf * di.fbs)
+        beta = np.zeros(self.nc * di.cbs)
+        sol = np.ascontiguousarray(solution, dtype=np.float64)
+        lib().hho_obstacle_expand_solution(di, self.nc, self.nf, _u8p(self.is_dir), _i64p(self.compress), _u8p(self.in_A),
+                                           _dp(sol), _dp(self.g), _dp(gamma), _dp(alpha), _dp(beta))
+        return alpha, beta
+
+    def take_local_data(self, c, expanded):
+        out = np.zeros(self.di.msize)
+        fids = np.ascontiguousarray(self.cell_faces[c])
+        lib().hho_obstacle_take_local_data(self.di, c, self.nc, _u64p(fids), _dp(expanded), _dp(out))
+        return out
 
 
 class CutMesh:
