@@ -168,7 +168,8 @@ int pa_assembler_query(pa_context *ctx, pa_degree_info di, pa_assembler_info *ou
  * PA_FN_SAMPLED d_fvals holds the function at the face quadrature points (nfaces_local x
  * (face_deg+1), the points come from pa_face_quadrature_points). */
 int pa_dirichlet_data_batch(pa_context *ctx, int face_deg, int fn, const double *d_fvals, double *d_g);
-/* integrate(msh, fc, 2*face_deg) quadratures.hpp:404-432: d_xyw[f][face_deg+1][3] */
+/* integrate(msh, fc, 2*face_deg) quadratures.hpp:404-432: d_xyw[f][face_deg+1][3]; face_deg <= 4
+ * (pass face_deg + di for the points of a degree-increased rule, utils.hpp:185) */
 int pa_face_quadrature_points(pa_context *ctx, int face_deg, double *d_xyw);
 
 /* assembler::assemble (hho.hpp:344-406) for cells [first, first+n): per cell msize^2 triplet
@@ -188,6 +189,21 @@ int pa_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n
  * (pa_dirichlet_data_batch; NULL = homogeneous). */
 int pa_take_local_data_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n,
                              const double *d_solution, const double *d_g, double *d_out);
+
+/* project_function(msh, cl, hdi, f, di) (utils.hpp:199-227) for cells [first, first+n):
+ * d_out n x msize = L2 projection of f on the cell basis (mass and rhs at degree
+ * 2*(cell_deg + dinc)) followed by the projections on the four faces (degree
+ * 2*(face_deg + dinc)).  fn = PA_FN_*; with PA_FN_SAMPLED d_cell_fvals holds f at the points of
+ * pa_cell_quadrature_points(2*(cell_deg+dinc)) for those cells and d_face_fvals at the points
+ * of pa_face_quadrature_points(face_deg + dinc) for every face of the context. d_info (n, may be
+ * NULL): first non-positive pivot of the cell mass matrix (+1), 0 if SPD. */
+int pa_project_function_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int dinc, int fn,
+                              const double *d_cell_fvals, const double *d_face_fvals,
+                              size_t first, size_t n, double *d_out, int32_t *d_info);
+/* d_out[c] = (u_c - v_c)^T lc_c (u_c - v_c) for n cells (the energy-error summand of
+ * convergence_test.cpp:283-300 / obstacle.cpp:202-213); d_v may be NULL (v = 0). */
+int pa_energy_form_batch(pa_context *ctx, pa_degree_info di, size_t n, const double *d_lc, const double *d_u,
+                         const double *d_v, double *d_out);
 
 /* ---- obstacle_assembler<Mesh> (hho.hpp:471-751) ---------------------------------------------
  * These entry points need the whole mesh on the context (no row slab).

@@ -107,7 +107,7 @@ class BatchAssembler:
         return g
 
     def face_quadrature_points(self, fd):
-        info = self.assembler_info(fd, fd)
+        info = self.assembler_info(0, 0)
         out = torch.empty((info.nfaces_local, fd + 1, 3), dtype=torch.float64, device=self.device)
         self.ctx.face_quadrature_points(fd, out.data_ptr())
         return out
@@ -132,6 +132,22 @@ class BatchAssembler:
         ms = (cd + 1) * (cd + 2) // 2 + 4 * (fd + 1)
         out = torch.empty((n, ms), dtype=torch.float64, device=self.device)
         self.ctx.take_local_data(di, first, n, solution.data_ptr(), _ptr(g), out.data_ptr())
+        return out
+
+    def project_function(self, cd, fd, fn, quad=capi.QUAD_TENSOR, dinc=0, cell_fvals=None, face_fvals=None, first=0, n=None):
+        """project_function(msh, cl, hdi, f, di) (utils.hpp:199-227) -> n x msize."""
+        di, _ = capi.degree_info(cd, fd)
+        n = self.ncells - first if n is None else n
+        ms = (di.cell_deg + 1) * (di.cell_deg + 2) // 2 + 4 * (di.face_deg + 1)
+        out = torch.empty((n, ms), dtype=torch.float64, device=self.device)
+        self.ctx.project_function(di, quad, dinc, fn, _ptr(cell_fvals), _ptr(face_fvals), first, n, out.data_ptr(), None)
+        return out
+
+    def energy_form(self, cd, fd, lc, u, v=None):
+        """per-cell (u - v)^T lc (u - v)."""
+        di, _ = capi.degree_info(cd, fd)
+        out = torch.empty(lc.shape[0], dtype=torch.float64, device=self.device)
+        self.ctx.energy_form(di, lc.shape[0], lc.data_ptr(), u.data_ptr(), _ptr(v), out.data_ptr())
         return out
 
     # ---- obstacle_assembler (hho.hpp:471-751) -------------------------------------------

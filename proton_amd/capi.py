@@ -25,7 +25,7 @@ EXPORTS = [
     "pa_local_ops_batch", "pa_cell_rhs_batch", "pa_cell_quadrature_points",
     "pa_static_condensation_batch", "pa_local_ops_launch_info",
     "pa_mesh_set_faces", "pa_assembler_query", "pa_dirichlet_data_batch", "pa_face_quadrature_points",
-    "pa_triplets_batch", "pa_take_local_data_batch",
+    "pa_triplets_batch", "pa_take_local_data_batch", "pa_project_function_batch", "pa_energy_form_batch",
     "pa_obstacle_tables", "pa_obstacle_triplets_batch", "pa_obstacle_expand_solution",
     "pa_obstacle_take_local_data_batch",
     "pa_cut_preprocess", "pa_cut_query", "pa_cut_local_ops_batch", "pa_cut_merge",
@@ -116,6 +116,8 @@ def lib():
     L.pa_face_quadrature_points.argtypes = [vp, C.c_int, dp]
     L.pa_triplets_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp, dp, dp, dp, dp, dp]
     L.pa_take_local_data_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp]
+    L.pa_project_function_batch.argtypes = [vp, DegreeInfo, C.c_int, C.c_int, C.c_int, dp, dp, sz, sz, dp, dp]
+    L.pa_energy_form_batch.argtypes = [vp, DegreeInfo, sz, dp, dp, dp, dp]
     L.pa_obstacle_tables.argtypes = [vp, vp, vp, vp, C.POINTER(sz), C.POINTER(sz)]
     L.pa_obstacle_triplets_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp, dp, vp, vp, vp, sz, dp, dp, dp, dp, dp]
     L.pa_obstacle_expand_solution.argtypes = [vp, DegreeInfo, dp, dp, dp, vp, vp, vp, sz, dp, dp]
@@ -235,6 +237,13 @@ class Context:
 
     def take_local_data(self, di, first, n, solution, g, out):
         self._ck(self._L.pa_take_local_data_batch(self.h, di, first, n, solution, g, out), "pa_take_local_data_batch")
+
+    def project_function(self, di, quad, dinc, fn, cell_fvals, face_fvals, first, n, out, info):
+        self._ck(self._L.pa_project_function_batch(self.h, di, quad, dinc, fn, cell_fvals, face_fvals, first, n, out, info),
+                 "pa_project_function_batch")
+
+    def energy_form(self, di, n, lc, u, v, out):
+        self._ck(self._L.pa_energy_form_batch(self.h, di, n, lc, u, v, out), "pa_energy_form_batch")
 
     def obstacle_tables(self, in_A, A_ct, B_ct):
         ni, na = C.c_size_t(0), C.c_size_t(0)

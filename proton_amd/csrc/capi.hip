@@ -403,7 +403,7 @@ int pa_dirichlet_data_batch(pa_context *ctx, int face_deg, int fn, const double 
 
 int pa_face_quadrature_points(pa_context *ctx, int face_deg, double *d_xyw)
 {
-    if (!ctx || !d_xyw || face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_ARG;
+    if (!ctx || !d_xyw || face_deg < 0 || face_deg > 4) return PA_ERR_INVALID_ARG;
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
     const uint32_t nf = (uint32_t)ctx->nfaces_local;
     hipLaunchKernelGGL(pa::face_qpoints_kernel, dim3((nf + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_tab,
@@ -659,6 +659,26 @@ static int launch_rhs(pa_context *ctx, int degree, int qdeg, int nqp, int fn, co
     return PA_OK;
 }
 
+template <int QUAD>
+static int launch_project(pa_context *ctx, int degree, int qdeg, int nqp, int fn, const double *d_fvals, size_t first,
+                          size_t n, double *d_out, int stride, int32_t *d_info)
+{
+    const int block = 256;
+    const int grid = (int)((n + block - 1) / block);
+#define PA_PROJ_CASE(D)                                                                                    \
+    case D:                                                                                                \
+        hipLaunchKernelGGL((pa::cell_project_kernel<D, QUAD>), dim3(grid), dim3(block), 0, ctx->stream, ctx->d_tab, \
+                           ctx->d_points, ctx->d_ptids, first, n, qdeg, nqp, fn, d_fvals, d_out, stride, d_info); \
+        break;
+    switch (degree) {
+        PA_PROJ_CASE(0) PA_PROJ_CASE(1) PA_PROJ_CASE(2) PA_PROJ_CASE(3) PA_PROJ_CASE(4)
+    default: return PA_ERR_INVALID_DEGREE;
+    }
+#undef PA_PROJ_CASE
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
 extern "C" {
 
 static int rhs_quadrature(pa_context *ctx, int qdeg, int quad_kind, int *nqp)
@@ -686,6 +706,54 @@ int pa_cell_rhs_batch(pa_context *ctx, int degree, int dinc, int quad_kind, int 
     if (n == 0) return PA_OK;
     return quad_kind == PA_QUAD_TENSOR ? launch_rhs<pa::QUAD_TENSOR>(ctx, degree, qdeg, nqp, fn, d_fvals, first, n, d_rhs)
                                        : launch_rhs<pa::QUAD_FAN>(ctx, degree, qdeg, nqp, fn, d_fvals, first, n, d_rhs);
+}
+
+int pa_project_function_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int dinc, int fn,
+                              const double *d_cell_fvals, const double *d_face_fvals, size_t first, size_t n,
+                              double *d_out, int32_t *d_info)
+{
+    if (!ctx || !d_out || dinc < 0) return PA_ERR_INVALID_ARG;
+    if (di.cell_deg < 0 || di.cell_deg > 4 || di.face_deg < 0 || di.face_deg > 3) return PA_ERR_INVALID_DEGREE;
+    if (!ctx->d_points) return PA_ERR_NO_MESH;
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
+    if (fn < PA_FN_SAMPLED || fn > PA_FN_ONE || (fn == PA_FN_SAMPLED && (!d_cell_fvals || !d_face_fvals))) return PA_ERR_INVALID_ARG;
+    const int qdeg = 2 * (di.cell_deg + dinc);                      // utils.hpp:123,165
+    int nqp = 0;
+    int st = rhs_quadrature(ctx, qdeg, quad_kind, &nqp);
+    if (st != PA_OK) return st;
+    const int nfq = di.face_deg + dinc + 1;                         // integrate(msh, fc, 2*(facdeg+di))
+    if (nfq > 5) return PA_ERR_QUADRATURE;
+    if (n == 0) return PA_OK;
+    const int cbs = pa::P2(di.cell_deg), msize = cbs + 4 * (di.face_deg + 1);
+    st = quad_kind == PA_QUAD_TENSOR
+             ? launch_project<pa::QUAD_TENSOR>(ctx, di.cell_deg, qdeg, nqp, fn, d_cell_fvals, first, n, d_out, msize, d_info)
+             : launch_project<pa::QUAD_FAN>(ctx, di.cell_deg, qdeg, nqp, fn, d_cell_fvals, first, n, d_out, msize, d_info);
+    if (st != PA_OK) return st;
+    const int grid = (int)((4 * n + 255) / 256);
+#define PA_FPROJ_CASE(D)                                                                                   \
+    case D:                                                                                                \
+        hipLaunchKernelGGL((pa::face_project_kernel<D>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_tab, ctx->d_points, \
+                           ctx->d_face_pts, ctx->d_cell_faces, first, n, nfq, fn, d_face_fvals, d_out, msize, cbs); \
+        break;
+    switch (di.face_deg) { PA_FPROJ_CASE(0) PA_FPROJ_CASE(1) PA_FPROJ_CASE(2) PA_FPROJ_CASE(3) }
+#undef PA_FPROJ_CASE
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
+int pa_energy_form_batch(pa_context *ctx, pa_degree_info di, size_t n, const double *d_lc, const double *d_u,
+                         const double *d_v, double *d_out)
+{
+    if (!ctx || !d_lc || !d_u || !d_out) return PA_ERR_INVALID_ARG;
+    if (di.cell_deg < 0 || di.cell_deg > 4 || di.face_deg < 0 || di.face_deg > 3) return PA_ERR_INVALID_DEGREE;
+    if (n == 0) return PA_OK;
+    const int msize = pa::P2(di.cell_deg) + 4 * (di.face_deg + 1);
+    const size_t resident = (size_t)ctx->num_cus * 32;
+    hipLaunchKernelGGL(pa::energy_form_kernel, dim3((unsigned)(n < resident ? n : resident)), dim3(64), 0, ctx->stream, n, msize,
+                       d_lc, d_u, d_v, d_out);
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
 }
 
 int pa_cell_quadrature_points(pa_context *ctx, int degree, int quad_kind, size_t first, size_t n, double *d_xyw,

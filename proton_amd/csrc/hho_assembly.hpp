@@ -258,6 +258,99 @@ __global__ __launch_bounds__(256) void take_local_data_kernel(TakeArgs a)
     a.out[t] = v;
 }
 
+// Face part of project_function (utils.hpp:216-222): for local face lf of a cell,
+// make_mass_matrix(fc, facdeg, di).llt().solve(make_rhs(fc, facdeg, f, di)).  At the Gauss point
+// t_q of the face (parameter running from the lower-id endpoint, bases.hpp:255-272) the basis is
+// t_q^k, and |F|/2 cancels between the two sides.  One thread per (cell, local face).
+template <int FD>
+__global__ __launch_bounds__(256) void face_project_kernel(const QuadTables *tab, const double *points,
+                                                           const uint32_t *face_pts, const uint32_t *cell_faces,
+                                                           size_t first, size_t n, int nfq, int fn, const double *fvals,
+                                                           double *out, int out_stride, int out_offset)
+{
+    constexpr int FBS = FD + 1;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 4 * n) return;
+    const size_t c = t / 4; const int lf = (int)(t % 4);
+    const uint32_t f = cell_faces[4 * (first + c) + lf];
+    const double2 a = *reinterpret_cast<const double2 *>(points + 2 * (size_t)face_pts[2 * f]);
+    const double2 b = *reinterpret_cast<const double2 *>(points + 2 * (size_t)face_pts[2 * f + 1]);
+    double M[FBS][FBS], x[FBS];
+#pragma unroll
+    for (int i = 0; i < FBS; ++i) {
+        x[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < FBS; ++j) M[i][j] = 0.0;
+    }
+    for (int q = 0; q < nfq; ++q) {
+        const double tq = tab->gauss_x[nfq][q], wq = tab->gauss_w[nfq][q];
+        const double px = 0.5 * (1 - tq) * a.x + 0.5 * (1 + tq) * b.x;
+        const double py = 0.5 * (1 - tq) * a.y + 0.5 * (1 + tq) * b.y;
+        const double fv = fn == FN_SAMPLED ? fvals[(size_t)f * nfq + q] : builtin_fn(fn, px, py);
+        double phi[FBS];
+        phi[0] = 1.0;
+#pragma unroll
+        for (int k = 1; k < FBS; ++k) phi[k] = phi[k - 1] * tq;
+#pragma unroll
+        for (int i = 0; i < FBS; ++i) {
+            x[i] += wq * phi[i] * fv;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) M[i][j] += wq * phi[i] * phi[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < FBS; ++j) {
+        double d = M[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= M[j][k] * M[j][k];
+        const double r = 1.0 / sqrt(d);
+        M[j][j] = r;
+#pragma unroll
+        for (int i = j + 1; i < FBS; ++i) {
+            double s = M[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= M[i][k] * M[j][k];
+            M[i][j] = s * r;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FBS; ++i) {
+        double s = x[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= M[i][k] * x[k];
+        x[i] = s * M[i][i];
+    }
+#pragma unroll
+    for (int i = FBS - 1; i >= 0; --i) {
+        double s = x[i];
+#pragma unroll
+        for (int k = i + 1; k < FBS; ++k) s -= M[k][i] * x[k];
+        x[i] = s * M[i][i];
+    }
+#pragma unroll
+    for (int k = 0; k < FBS; ++k) out[c * out_stride + out_offset + lf * FBS + k] = x[k];
+}
+
+// diff.dot(lc * diff) per cell (the energy error of convergence_test.cpp / obstacle.cpp:202-213):
+// one wavefront per cell, lc read once with coalesced loads.
+__global__ __launch_bounds__(64) void energy_form_kernel(size_t n, int msize, const double *lc, const double *u,
+                                                         const double *v, double *out)
+{
+    __shared__ double d[64];
+    const int l = threadIdx.x;
+    for (size_t c = blockIdx.x; c < n; c += gridDim.x) {
+        if (l < msize) d[l] = u[c * msize + l] - (v ? v[c * msize + l] : 0.0);
+        __syncthreads();
+        const double *A = lc + c * (size_t)(msize * msize);
+        double s = 0.0;
+        for (int e = l; e < msize * msize; e += 64) s += A[e] * d[e % msize] * d[e / msize];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (l == 0) out[c] = s;
+        __syncthreads();
+    }
+}
+
 // ---- obstacle_assembler (hho.hpp:471-751) ----------------------------------------------------
 // compress tables A_ct / B_ct (hho.hpp:538-578) = exclusive prefix counts of the cells outside /
 // inside the active set: a three-pass scan (per-block counts, scan of the block counts by one

@@ -181,6 +181,84 @@ __global__ __launch_bounds__(256) void cell_rhs_kernel(const QuadTables *tab, co
     for (int m = 0; m < CBS; ++m) rhs[t * CBS + m] = acc[m];
 }
 
+// Cell part of project_function(msh, cl, hdi, f, di) (utils.hpp:199-214): mass and right-hand
+// side at degree 2*(celdeg + di), then mass.llt().solve(rhs).  One thread per cell (a postprocess
+// kernel: the packed lower triangle of the mass matrix lives in per-thread memory).
+template <int DEG, int QUAD>
+__global__ __launch_bounds__(256) void cell_project_kernel(const QuadTables *tab, const double *points,
+                                                           const uint32_t *ptids, size_t first, size_t n,
+                                                           int qdegree, int nqp, int fn, const double *fvals,
+                                                           double *out, int out_stride, int32_t *info)
+{
+    constexpr int CBS = P2(DEG);
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    CellGeom c;
+    load_cell_geom(points, ptids, first + t, c);
+    const double ihalf = 1.0 / (0.5 * c.hT);
+    double b[CBS], M[CBS * (CBS + 1) / 2];
+#pragma unroll
+    for (int m = 0; m < CBS; ++m) b[m] = 0.0;
+#pragma unroll
+    for (int m = 0; m < CBS * (CBS + 1) / 2; ++m) M[m] = 0.0;
+    for (int q = 0; q < nqp; ++q) {
+        double x, y, w;
+        cell_qp<QUAD>(tab, c, qdegree, q, x, y, w);
+        const double fv = (fn == FN_SAMPLED) ? fvals[t * nqp + q] : builtin_fn(fn, x, y);
+        const double bx = (x - c.barx) * ihalf, by = (y - c.bary) * ihalf;
+        double pwx[DEG + 1], pwy[DEG + 1], phi[CBS];
+        pwx[0] = 1.0; pwy[0] = 1.0;
+#pragma unroll
+        for (int e = 1; e <= DEG; ++e) { pwx[e] = pwx[e - 1] * bx; pwy[e] = pwy[e - 1] * by; }
+        int m = 0;
+#pragma unroll
+        for (int kk = 0; kk <= DEG; ++kk)
+#pragma unroll
+            for (int ii = 0; ii <= kk; ++ii, ++m) phi[m] = pwx[kk - ii] * pwy[ii];
+#pragma unroll
+        for (int i = 0; i < CBS; ++i) {
+            const double wp = w * phi[i];
+            b[i] += wp * fv;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] += wp * phi[j];
+        }
+    }
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < CBS; ++j) {                                  // unpivoted lower Cholesky, like Eigen's LLT
+        double d = M[j * (j + 1) / 2 + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= M[j * (j + 1) / 2 + k] * M[j * (j + 1) / 2 + k];
+        if (!(d > 0.0) && bad == 0) bad = j + 1;
+        const double r = 1.0 / sqrt(d);
+        M[j * (j + 1) / 2 + j] = r;                                  // reciprocal of the diagonal
+#pragma unroll
+        for (int i = j + 1; i < CBS; ++i) {
+            double s = M[i * (i + 1) / 2 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= M[i * (i + 1) / 2 + k] * M[j * (j + 1) / 2 + k];
+            M[i * (i + 1) / 2 + j] = s * r;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CBS; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= M[i * (i + 1) / 2 + k] * b[k];
+        b[i] = s * M[i * (i + 1) / 2 + i];
+    }
+#pragma unroll
+    for (int i = CBS - 1; i >= 0; --i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < CBS; ++k) s -= M[k * (k + 1) / 2 + i] * b[k];
+        b[i] = s * M[i * (i + 1) / 2 + i];
+    }
+#pragma unroll
+    for (int m = 0; m < CBS; ++m) out[t * out_stride + m] = b[m];
+    if (info != nullptr) info[t] = bad;
+}
+
 // Static condensation, one wavefront per cell (not on the reference's path; used by the
 // face-DOF triplet path of the multi-GPU exchange).  A = lc (MS x MS), T = first CBS dofs.
 //   rec = A_TT^-1 [ f_T | -A_TF ],  S = A_FF + A_FT rec[:,1:],  g = -A_FT rec[:,0]

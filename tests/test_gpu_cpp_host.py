@@ -13,6 +13,38 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _compile(name):
+    out_dir = os.path.join(ROOT, "tests", "cpp", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, name)
+    lib_dir = os.path.join(ROOT, "proton_amd", "lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
+           "-L" + lib_dir, "-lproton_amd", "-Wl,-rpath," + lib_dir]
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+@pytest.fixture(scope="module")
+def obstacle_driver():
+    return _compile("obstacle_driver")
+
+
+@pytest.mark.parametrize("degree,N,mode", [(0, 8, None), (1, 8, None), (1, 16, "batched"), (0, 16, "batched")])
+def test_obstacle_driver_reproduces_committed_results(obstacle_driver, degree, N, mode):
+    """apps/obstacle through the drop-in header (make_obstacle_assembler, assemble, expand_solution,
+    take_local_data, project_function) reproduces apps/obstacle/results/convergence.txt; the per-cell
+    API and the batched device assembler give the same numbers."""
+    REF = {8: (2.26205, 0.197735), 16: (1.2833, 0.0588187)}
+    args = [obstacle_driver, str(degree), str(N)] + ([mode] if mode else [])
+    r = subprocess.run(args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"iterations (\d+) error ([0-9.e+-]+)", r.stdout)
+    assert m, r.stdout
+    assert int(m.group(1)) < 50
+    err = float(m.group(2))
+    assert abs(err - REF[N][degree]) / REF[N][degree] < 5e-6, r.stdout
+
+
 @pytest.fixture(scope="module")
 def driver():
     out_dir = os.path.join(ROOT, "tests", "cpp", "build")

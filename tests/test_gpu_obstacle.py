@@ -124,6 +124,43 @@ def test_take_local_data_of_the_plain_assembler(asm, oracle, N, cd, fd):
         assert np.array_equal(got[cell], want)
 
 
+@pytest.mark.parametrize("N,cd,fd,dinc,quad", [(5, 0, 1, 1, 0), (4, 2, 1, 0, 0), (3, 3, 2, 1, 0), (3, 4, 3, 0, 0), (4, 2, 1, 0, 1), (3, 0, 0, 2, 0)])
+def test_project_function_and_energy_form(asm, oracle, N, cd, fd, dinc, quad):
+    """project_function (utils.hpp:199-227) against the oracle, and diff.dot(lc*diff) per cell."""
+    import proton_amd as pa
+    from proton_amd.batch import to_rowcol
+    asm.generate_mesh(N, N, (-1.0, -1.0), (1.0, 1.0))
+    got = asm.project_function(cd, fd, pa.capi.FN_OBSTACLE_SOL, quad=quad, dinc=dinc).cpu().numpy()
+    mp, points, ptids = oracle.make_mesh(N, N, (-1.0, -1.0), (1.0, 1.0))
+    di = oracle.degrees(cd, fd)
+    worst = 0.0
+    sol_host = lambda x, y: max(x * x + y * y - 0.7 * 0.7, 0.0) ** 2          # obstacle.cpp:76-81
+    for c in range(N * N):
+        pts = points[ptids[c].astype(np.int64)]
+        st, want = oracle.project_function(pts, ptids[c], di, sol_host, quad=quad, dinc=dinc)
+        assert st == 0
+        worst = max(worst, np.abs(got[c] - want).max() / max(1.0, np.abs(want).max()))
+    assert worst < 1e-12, worst
+    # sampled functor path == built-in path
+    import torch
+    nq = asm.quadrature_points(2 * (di.cell_deg + dinc), quad)
+    fq = asm.face_quadrature_points(di.face_deg + dinc)
+    sol = lambda xy: torch.clamp(xy[..., 0] ** 2 + xy[..., 1] ** 2 - 0.7 * 0.7, min=0.0) ** 2
+    got2 = asm.project_function(cd, fd, pa.capi.FN_SAMPLED, quad=quad, dinc=dinc, cell_fvals=sol(nq).contiguous(),
+                                face_fvals=sol(fq).contiguous()).cpu().numpy()
+    assert np.abs(got2 - got).max() < 1e-12
+    if quad == 0:
+        lc = asm.local_ops(cd, fd, pa.QUAD_TENSOR, pa.STAB_FANCY, want=("lc",))["lc"]
+        rng = np.random.default_rng(5)
+        u = rng.standard_normal(got.shape)
+        e = asm.energy_form(cd, fd, lc, _dev(u, asm), _dev(got, asm)).cpu().numpy()
+        L = to_rowcol(lc)
+        want_e = np.einsum("ci,cij,cj->c", u - got, L, u - got)
+        assert np.abs(e - want_e).max() <= 1e-12 * np.abs(want_e).max()
+        e0 = asm.energy_form(cd, fd, lc, _dev(u, asm)).cpu().numpy()
+        assert np.abs(e0 - np.einsum("ci,cij,cj->c", u, L, u)).max() <= 1e-12 * np.abs(e0).max()
+
+
 class GpuObstacleAssembler:
     """The shape tests/obstacle_driver.run_obstacle expects, over the C ABI."""
 
