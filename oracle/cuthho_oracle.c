@@ -4,6 +4,7 @@
  */
 #include "cuthho_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -608,4 +609,235 @@ int cut_make_rhs(const cut_mesh *m, const cut_level_set *ls, size_t c, int degre
             rhs[i] += (qw[q] * bv) * (phi[i] * CELL_ETA / hT - (gx[i] * n[0] + gy[i] * n[1]));      /* :654 */
     }
     return HHO_OK;
+}
+
+/* ---- two-sided interface problem ----------------------------------------------------------- */
+/* LDL^T with symmetric diagonal pivoting (what Eigen's LDLT computes, cuthho_square.cpp:498):
+ * P A P^T = L D L^T, at step k the largest remaining |diagonal| entry is moved to position k.
+ * solve: x = P^T L^-T D^+ L^-1 P b, D^+ the pseudo-inverse of D (tolerance: see ldlt_solve). */
+static void ldlt_factor(double *A, int n, int *perm)
+{
+    for (int i = 0; i < n; i++) perm[i] = i;
+    for (int k = 0; k < n; k++) {
+        int p = k;
+        for (int i = k + 1; i < n; i++)
+            if (fabs(A[IDX(i, i, n)]) > fabs(A[IDX(p, p, n)])) p = i;
+        if (p != k) {                                       /* symmetric swap of rows/columns k and p (full storage) */
+            for (int j = 0; j < n; j++) { double t = A[IDX(k, j, n)]; A[IDX(k, j, n)] = A[IDX(p, j, n)]; A[IDX(p, j, n)] = t; }
+            for (int i = 0; i < n; i++) { double t = A[IDX(i, k, n)]; A[IDX(i, k, n)] = A[IDX(i, p, n)]; A[IDX(i, p, n)] = t; }
+            int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
+        }
+        double d = A[IDX(k, k, n)];
+        if (d == 0.0) continue;
+        for (int i = k + 1; i < n; i++) A[IDX(i, k, n)] /= d;                     /* column of L */
+        for (int j = k + 1; j < n; j++)                                             /* trailing update */
+            for (int i = j; i < n; i++) {
+                A[IDX(i, j, n)] -= A[IDX(i, k, n)] * d * A[IDX(j, k, n)];
+                A[IDX(j, i, n)] = A[IDX(i, j, n)];
+            }
+    }
+}
+
+static void ldlt_solve(const double *F, int n, const int *perm, double *B, int nrhs)
+{
+    double y[2 * HHO_MAX_RBS];
+    /* pseudo-inverse of D.  Tolerance of Eigen <= 3.2 (max|D| * epsilon).  Eigen 3.3+ uses
+     * numeric_limits::min(): the semi-definite system's last pivot is rounding noise (1e-31 .. 1e-15
+     * here, rows 0 and rbs of gr_lhs being bitwise negatives of each other), which that tolerance
+     * inverts into an O(1e15) multiple of the kernel vector and destroys `data`; the committed
+     * cuthho.xlsx numbers are only reproduced with the kernel component suppressed. */
+    double dmax = 0.0;
+    for (int i = 0; i < n; i++) dmax = fmax(dmax, fabs(F[IDX(i, i, n)]));
+    const double tol = fmax(dmax * DBL_EPSILON, DBL_MIN);
+    for (int c = 0; c < nrhs; c++) {
+        double *b = B + (size_t)c * n;
+        for (int i = 0; i < n; i++) y[i] = b[perm[i]];
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < i; k++) y[i] -= F[IDX(i, k, n)] * y[k];
+        for (int i = 0; i < n; i++) y[i] = fabs(F[IDX(i, i, n)]) > tol ? y[i] / F[IDX(i, i, n)] : 0.0;
+        for (int i = n - 1; i >= 0; i--)
+            for (int k = i + 1; k < n; k++) y[i] -= F[IDX(k, i, n)] * y[k];
+        for (int i = 0; i < n; i++) b[perm[i]] = y[i];
+    }
+}
+
+int cut_make_hho_laplacian_interface(const cut_mesh *m, const cut_level_set *ls, size_t c, hho_degrees di,
+                                     const cut_params *parms, double *oper, double *data)
+{
+    if (m->cell_loc[c] != CUT_ON_INTERFACE) return HHO_ERR_ARG;        /* :397-398 "The cell is not cut" */
+    double pts[8]; uint64_t ids[4];
+    cell_pts(m, c, pts, ids);
+    int recdeg = di.rec_deg, celdeg = di.cell_deg, facdeg = di.face_deg;
+    int rbs = hho_cell_basis_size(recdeg), cbs = hho_cell_basis_size(celdeg), fbs = hho_face_basis_size(facdeg);
+    int msize = cbs + 4 * fbs, n2 = 2 * rbs, m2 = 2 * msize;
+    if (recdeg > HHO_MAX_RECDEG || cbs > rbs) return HHO_ERR_DEGREE;
+    double bar[2]; hho_cell_barycenter(pts, bar);
+    double h = hho_cell_diameter(pts);
+    static double stiff[4 * HHO_MAX_RBS * HHO_MAX_RBS], gr_lhs[4 * HHO_MAX_RBS * HHO_MAX_RBS];
+    static double gr_rhs[4 * HHO_MAX_RBS * HHO_MAX_MSIZE];
+    memset(stiff, 0, sizeof(double) * n2 * n2);
+    memset(gr_rhs, 0, sizeof(double) * n2 * m2);
+    static double qx[CUT_MAX_QPS], qy[CUT_MAX_QPS], qw[CUT_MAX_QPS];
+    double gx[HHO_MAX_RBS], gy[HHO_MAX_RBS], phi[HHO_MAX_RBS], fphi[HHO_MAX_FBS];
+    const double kappa[2] = { parms->kappa_1, parms->kappa_2 };
+
+    for (int side = 0; side < 2; side++) {                              /* :419-432 */
+        int nq = cut_cell_quadrature(m, c, 2 * recdeg, side == 0 ? CUT_NEG : CUT_POS, qx, qy, qw, CUT_MAX_QPS);
+        if (nq < 0) return -nq;
+        int o = side * rbs;
+        for (int q = 0; q < nq; q++) {
+            hho_cell_basis_grad(bar, h, recdeg, qx[q], qy[q], gx, gy);
+            for (int j = 0; j < rbs; j++)
+                for (int i = 0; i < rbs; i++)
+                    stiff[IDX(o + i, o + j, n2)] += kappa[side] * ((qw[q] * gx[i]) * gx[j] + (qw[q] * gy[i]) * gy[j]);
+        }
+    }
+    double hT = hho_cell_measure(pts);                                  /* :434 */
+    int nq = cut_interface_quadrature(m, c, 2 * recdeg, CUT_NEG, qx, qy, qw, CUT_MAX_QPS);   /* :437 */
+    if (nq < 0) return -nq;
+    for (int q = 0; q < nq; q++) {
+        double n[2];
+        hho_cell_basis_eval(bar, h, recdeg, qx[q], qy[q], phi);
+        hho_cell_basis_grad(bar, h, recdeg, qx[q], qy[q], gx, gy);
+        cut_ls_normal(ls, qx[q], qy[q], n);
+        for (int j = 0; j < rbs; j++) {
+            double dnj = gx[j] * n[0] + gy[j] * n[1];
+            for (int i = 0; i < rbs; i++) {
+                double dni = gx[i] * n[0] + gy[i] * n[1];
+                double a = parms->kappa_1 * qw[q] * phi[i] * dnj;                 /* :444 */
+                double b = parms->kappa_1 * qw[q] * dni * phi[j];                 /* :445 */
+                double cc = parms->kappa_1 * qw[q] * phi[i] * phi[j] * parms->eta / hT;   /* :446 */
+                stiff[IDX(i, j, n2)] -= a;           stiff[IDX(rbs + i, j, n2)] += a;     /* :448-449 */
+                stiff[IDX(i, j, n2)] -= b;           stiff[IDX(i, rbs + j, n2)] += b;     /* :451-452 */
+                stiff[IDX(i, j, n2)] += cc;          stiff[IDX(i, rbs + j, n2)] -= cc;    /* :454-457 */
+                stiff[IDX(rbs + i, j, n2)] -= cc;    stiff[IDX(rbs + i, rbs + j, n2)] += cc;
+            }
+        }
+    }
+    memcpy(gr_lhs, stiff, sizeof(double) * n2 * n2);                    /* :461 */
+    for (int j = 0; j < cbs; j++)                                       /* :462-463 */
+        for (int i = 0; i < n2; i++) {
+            gr_rhs[IDX(i, j, n2)] = stiff[IDX(i, j, n2)];
+            gr_rhs[IDX(i, cbs + j, n2)] = stiff[IDX(i, rbs + j, n2)];
+        }
+    double nrm[8]; hho_cell_normals(pts, nrm);
+    for (int f = 0; f < 4; f++) {                                       /* :465-495 */
+        double fp0[2], fp1[2];
+        hho_cell_face_points(pts, ids, f, fp0, fp1);
+        for (int side = 0; side < 2; side++) {
+            double fx[HHO_MAX_GAUSS], fy[HHO_MAX_GAUSS], fw[HHO_MAX_GAUSS];
+            int nfq = cut_face_quadrature(m, c, f, 2 * recdeg, side == 0 ? CUT_NEG : CUT_POS, fx, fy, fw, HHO_MAX_GAUSS);
+            if (nfq < 0) return -nfq;
+            int ro = side * rbs, co_cell = side * cbs, co_face = 2 * cbs + side * 4 * fbs + f * fbs;   /* :480,492 */
+            for (int q = 0; q < nfq; q++) {
+                hho_cell_basis_eval(bar, h, recdeg, fx[q], fy[q], phi);
+                hho_cell_basis_grad(bar, h, recdeg, fx[q], fy[q], gx, gy);
+                hho_face_basis_eval(fp0, fp1, facdeg, fx[q], fy[q], fphi);
+                for (int i = 0; i < rbs; i++) {
+                    double wdn = kappa[side] * fw[q] * (gx[i] * nrm[2 * f] + gy[i] * nrm[2 * f + 1]);
+                    for (int j = 0; j < cbs; j++) gr_rhs[IDX(ro + i, co_cell + j, n2)] -= wdn * phi[j];
+                    for (int j = 0; j < fbs; j++) gr_rhs[IDX(ro + i, co_face + j, n2)] += wdn * fphi[j];
+                }
+            }
+        }
+    }
+    int perm[2 * HHO_MAX_RBS];
+    ldlt_factor(gr_lhs, n2, perm);                                       /* :498 */
+    memcpy(oper, gr_rhs, sizeof(double) * n2 * m2);
+    ldlt_solve(gr_lhs, n2, perm, oper, m2);
+    for (int j = 0; j < m2; j++)                                         /* :499 */
+        for (int i = 0; i < m2; i++) {
+            double s = 0.0;
+            for (int k = 0; k < n2; k++) s += gr_rhs[IDX(k, i, n2)] * oper[IDX(k, j, n2)];
+            data[IDX(i, j, m2)] = s;
+        }
+    return HHO_OK;
+}
+
+int cut_make_rhs_side(const cut_mesh *m, size_t c, int degree, int where, hho_scalar_fn f, void *user, double *rhs)
+{
+    double pts[8]; uint64_t ids[4];
+    cell_pts(m, c, pts, ids);
+    int cbs = hho_cell_basis_size(degree);
+    memset(rhs, 0, sizeof(double) * cbs);
+    double bar[2]; hho_cell_barycenter(pts, bar);
+    double h = hho_cell_diameter(pts);
+    static double qx[CUT_MAX_QPS], qy[CUT_MAX_QPS], qw[CUT_MAX_QPS];
+    double phi[HHO_MAX_RBS];
+    int nq = cut_cell_quadrature(m, c, 2 * degree, where, qx, qy, qw, CUT_MAX_QPS);    /* cuthho_utils.hpp:75 */
+    if (nq < 0) return -nq;
+    for (int q = 0; q < nq; q++) {
+        hho_cell_basis_eval(bar, h, degree, qx[q], qy[q], phi);
+        double fv = f(qx[q], qy[q], user);
+        for (int i = 0; i < cbs; i++) rhs[i] += (qw[q] * phi[i]) * fv;
+    }
+    return HHO_OK;
+}
+
+void cut_interface_tables(const cut_mesh *m, int64_t *cell_table, int64_t *face_table,
+                          size_t *num_all_cells, size_t *num_other_faces)
+{
+    size_t nc = 0;
+    for (size_t c = 0; c < m->nc; c++) {                             /* :1142-1150 */
+        cell_table[c] = (int64_t)nc;
+        nc += m->cell_loc[c] == CUT_ON_INTERFACE ? 2 : 1;
+    }
+    size_t co = 0;
+    for (size_t f = 0; f < m->nf; f++) {                             /* :1167-1178 */
+        if (m->face_bnd[f]) { face_table[f] = -1; continue; }            /* every boundary face is Dirichlet */
+        face_table[f] = (int64_t)co;
+        co += m->face_loc[f] == CUT_ON_INTERFACE ? 2 : 1;
+    }
+    *num_all_cells = nc;
+    *num_other_faces = co;   /* == num_all_faces - num_dirichlet_faces (:1162-1163): cut faces are never on the boundary */
+}
+
+int cut_interface_assemble(const cut_mesh *m, hho_degrees di, size_t c, const int64_t *cell_table,
+                           const int64_t *face_table, size_t num_all_cells,
+                           const double *lhs, const double *rhs, const double *dirichlet_data,
+                           int32_t *trip_rows, int32_t *trip_cols, double *trip_vals, size_t *ntrip,
+                           int64_t *rhs_rows, double *rhs_vals)
+{
+    int cbs = hho_cell_basis_size(di.cell_deg), fbs = hho_face_basis_size(di.face_deg);
+    int msize = cbs + 4 * fbs;
+    int cut = m->cell_loc[c] == CUT_ON_INTERFACE;
+    int n = cut ? 2 * msize : msize;
+    int64_t idx[2 * HHO_MAX_MSIZE];
+    int assem[2 * HHO_MAX_MSIZE];
+    int64_t cell_LHS_offset = cell_table[c] * cbs;                       /* :1223, :1291 */
+    int ncd = cut ? 2 * cbs : cbs;
+    for (int i = 0; i < ncd; i++) { idx[i] = cell_LHS_offset + i; assem[i] = 1; }
+    for (int pass = 0; pass < (cut ? 2 : 1); pass++)                     /* :1230-1247 ; :1296-1333 */
+        for (int f = 0; f < 4; f++) {
+            size_t fid = m->cell_faces[4 * c + f];
+            int dirichlet = m->face_bnd[fid];
+            if (cut && dirichlet) return HHO_ERR_ARG;                    /* "Dirichlet boundary on cut cell not supported." */
+            int64_t d = (pass == 1 && m->face_loc[fid] == CUT_ON_INTERFACE) ? fbs : 0;    /* :1319 */
+            int64_t face_LHS_offset = (int64_t)num_all_cells * cbs + (dirichlet ? 0 : face_table[fid]) * fbs + d;
+            for (int i = 0; i < fbs; i++) {
+                idx[ncd + pass * 4 * fbs + f * fbs + i] = face_LHS_offset + i;
+                assem[ncd + pass * 4 * fbs + f * fbs + i] = !dirichlet;
+            }
+        }
+    size_t nt = 0;
+    for (int i = 0; i < n; i++) { rhs_rows[i] = assem[i] ? idx[i] : -1; rhs_vals[i] = 0.0; }
+    for (int i = 0; i < n; i++) {                                        /* :1251-1263 ; :1337-1347 */
+        if (!assem[i]) continue;
+        for (int j = 0; j < n; j++) {
+            double v = lhs[IDX(i, j, n)];
+            if (assem[j]) { trip_rows[nt] = (int32_t)idx[i]; trip_cols[nt] = (int32_t)idx[j]; trip_vals[nt] = v; nt++; }
+            else rhs_vals[i] -= v * dirichlet_data[j];
+        }
+    }
+    for (int i = 0; i < ncd; i++) rhs_vals[i] += rhs[i];                 /* :1265 ; :1349 */
+    *ntrip = nt;
+    return HHO_OK;
+}
+
+size_t cut_interface_cell_offset(const cut_mesh *m, hho_degrees di, size_t c, const int64_t *cell_table, int where)
+{
+    int cbs = hho_cell_basis_size(di.cell_deg);
+    size_t o = (size_t)cell_table[c] * cbs;                              /* :1368-1379 */
+    if (m->cell_loc[c] == CUT_ON_INTERFACE && where == CUT_POS) o += cbs;
+    return o;
 }

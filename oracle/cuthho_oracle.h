@@ -72,6 +72,38 @@ int cut_make_hho_cut_stabilization(const cut_mesh *m, size_t cell, hho_degrees d
 int cut_make_rhs(const cut_mesh *m, const cut_level_set *ls, size_t cell, int degree, int where,
                  hho_scalar_fn f, hho_scalar_fn bcs, void *user, double *rhs);
 
+/* ---- two-sided interface problem (`cuthho_square -i`) ------------------------------------- */
+typedef struct { double kappa_1, kappa_2, eta; } cut_params;   /* params<T>, cuthho_square.cpp:293-299: 1, 1, 5 */
+
+/* make_hho_laplacian_interface cuthho_square.cpp:390-502 for a CUT cell: unknowns ordered
+ * [cell-, cell+, faces-, faces+].  oper 2rbs x 2msize, data 2msize x 2msize (column-major).
+ * gr_lhs is symmetric positive SEMI-definite (kernel: the same constant on both sides) and the
+ * reference solves with Eigen's LDLT (diagonal pivoting, :498): restated here as textbook LDL^T with
+ * symmetric diagonal pivoting and a pseudo-inverse of the rounding-level pivot (max|D| * eps, the
+ * tolerance of Eigen <= 3.2; see ldlt_solve in the .c file for why not Eigen 3.3's).  `oper` is
+ * therefore the solution with zero component on the last pivot; `data = gr_rhs^T oper` (:499),
+ * the only output run_cuthho_interface uses (:1692), does not depend on the kernel component. */
+int cut_make_hho_laplacian_interface(const cut_mesh *m, const cut_level_set *ls, size_t cell, hho_degrees di,
+                                     const cut_params *parms, double *oper, double *data);
+/* make_rhs(msh, cl, degree, where, f) src/methods/cuthho_bits/cuthho_utils.hpp:65-84 */
+int cut_make_rhs_side(const cut_mesh *m, size_t cell, int degree, int where, hho_scalar_fn f, void *user, double *rhs);
+
+/* interface_assembler cuthho_square.cpp:1091-1443.  Tables of the constructor (:1137-1185):
+ * cell_table[c] = first unknown block of cell c (cut cells own two), face_table[f] = first
+ * block of non-Dirichlet face f (cut faces own two; -1 for Dirichlet faces). */
+void cut_interface_tables(const cut_mesh *m, int64_t *cell_table, int64_t *face_table,
+                          size_t *num_all_cells, size_t *num_other_faces);
+/* assemble (:1203-1269, uncut cell, lhs msize^2) / assemble_cut (:1271-1354, cut cell, lhs
+ * (2 msize)^2, rhs 2cbs): triplets in push order and per-local-row right-hand-side updates, like
+ * hho_assembler_assemble_cell.  dirichlet_data: msize values (uncut only). */
+int cut_interface_assemble(const cut_mesh *m, hho_degrees di, size_t cell, const int64_t *cell_table,
+                           const int64_t *face_table, size_t num_all_cells,
+                           const double *lhs, const double *rhs, const double *dirichlet_data,
+                           int32_t *trip_rows, int32_t *trip_cols, double *trip_vals, size_t *ntrip,
+                           int64_t *rhs_rows, double *rhs_vals);
+/* cell unknowns read back by take_local_data (:1356-1379): offset of the cell block of `where` */
+size_t cut_interface_cell_offset(const cut_mesh *m, hho_degrees di, size_t cell, const int64_t *cell_table, int where);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,10 @@ SCALAR_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_void_p)
 CUT_NEG, CUT_POS, CUT_ON_INTERFACE = 0, 1, 2
 
 
+class CutParams(C.Structure):
+    _fields_ = [("kappa_1", C.c_double), ("kappa_2", C.c_double), ("eta", C.c_double)]
+
+
 class CutLevelSet(C.Structure):
     _fields_ = [("kind", C.c_int), ("radius", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
                 ("cut_y", C.c_double)]
@@ -167,6 +171,14 @@ def lib():
     L.cut_cell_measure.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     L.cut_make_hho_laplacian.argtypes = [C.c_void_p, lsp, C.c_size_t, Degrees, C.c_int, dp, dp, C.POINTER(C.c_int)]
     L.cut_make_hho_cut_stabilization.argtypes = [C.c_void_p, C.c_size_t, Degrees, C.c_int, dp]
+    L.cut_make_hho_laplacian_interface.argtypes = [C.c_void_p, lsp, C.c_size_t, Degrees, C.POINTER(CutParams), dp, dp]
+    L.cut_make_rhs_side.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, SCALAR_FN, C.c_void_p, dp]
+    L.cut_interface_tables.restype = None
+    L.cut_interface_tables.argtypes = [C.c_void_p, i64p, i64p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.cut_interface_assemble.argtypes = [C.c_void_p, Degrees, C.c_size_t, i64p, i64p, C.c_size_t, dp, dp, dp,
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, C.POINTER(C.c_size_t), i64p, dp]
+    L.cut_interface_cell_offset.restype = C.c_size_t
+    L.cut_interface_cell_offset.argtypes = [C.c_void_p, Degrees, C.c_size_t, i64p, C.c_int]
     L.cut_make_rhs.argtypes = [C.c_void_p, lsp, C.c_size_t, C.c_int, C.c_int, SCALAR_FN, SCALAR_FN, C.c_void_p, dp]
     _LIB = L
     return L
@@ -498,3 +510,40 @@ class CutMesh:
         st = self.L.cut_make_rhs(self.h, C.byref(self.ls), c, degree, where, self.L.hho_builtin_fn(f_id),
                                  self.L.hho_builtin_fn(bcs_id), None, _dp(out))
         return st, out
+
+    # ---- two-sided interface problem (cuthho_square -i) ----
+    def laplacian_interface(self, c, di, kappa_1=1.0, kappa_2=1.0, eta=5.0):
+        """make_hho_laplacian_interface -> (status, oper 2rbs x 2msize, data 2msize x 2msize), row-major numpy."""
+        ms2, rb2 = 2 * di.msize, 2 * di.rbs
+        oper = np.zeros((ms2, rb2))
+        data = np.zeros((ms2, ms2))
+        prm = CutParams(kappa_1, kappa_2, eta)
+        st = self.L.cut_make_hho_laplacian_interface(self.h, C.byref(self.ls), c, di, C.byref(prm), _dp(oper), _dp(data))
+        return st, oper.T.copy(), data.T.copy()
+
+    def rhs_side(self, c, degree, where, f_id=1):
+        out = np.zeros((degree + 2) * (degree + 1) // 2)
+        st = self.L.cut_make_rhs_side(self.h, c, degree, where, self.L.hho_builtin_fn(f_id), None, _dp(out))
+        return st, out
+
+    def interface_tables(self):
+        ct = np.zeros(self.nc, dtype=np.int64)
+        ft = np.zeros(self.nf, dtype=np.int64)
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self.L.cut_interface_tables(self.h, _i64p(ct), _i64p(ft), C.byref(a), C.byref(b))
+        return ct, ft, a.value, b.value
+
+    def interface_assemble(self, di, c, cell_table, face_table, num_all_cells, lhs_rowcol, rhs, dirichlet_data):
+        n = lhs_rowcol.shape[0]
+        lhs = np.ascontiguousarray(lhs_rowcol.T)
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        dd = np.ascontiguousarray(dirichlet_data, dtype=np.float64)
+        tr = np.zeros(n * n, dtype=np.int32); tc = np.zeros(n * n, dtype=np.int32); tv = np.zeros(n * n)
+        nt = C.c_size_t(0)
+        rr = np.zeros(n, dtype=np.int64); rv = np.zeros(n)
+        st = self.L.cut_interface_assemble(self.h, di, c, _i64p(cell_table), _i64p(face_table), num_all_cells, _dp(lhs), _dp(rhs),
+                                           _dp(dd), tr.ctypes.data_as(C.POINTER(C.c_int32)), tc.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           _dp(tv), C.byref(nt), _i64p(rr), _dp(rv))
+        assert st == 0, st
+        k = nt.value
+        return tr[:k], tc[:k], tv[:k], rr, rv

@@ -30,6 +30,47 @@ def test_fictitious_domain_energy_error_matches_xlsx(k, r, N):
     assert abs(err - ref) / ref < 6e-6, (err, ref)          # 6 printed digits
 
 
+# cuthho.xlsx, "Interface" table: B23:D23, G23:I23, L23:N23 (r = 4) and row 24 (r = 5)
+INTERFACE = {
+    (0, 4): {10: 0.285023, 20: 0.143641, 40: 7.17622e-2},
+    (1, 4): {10: 2.01456e-2, 20: 5.22389e-3, 40: 1.33102e-3},
+    (2, 4): {10: 1.13312e-3, 20: 1.38029e-4, 40: 1.71019e-5},
+    (0, 5): {10: 0.285023, 20: 0.143641},
+    (1, 5): {10: 2.01455e-2, 20: 5.22388e-3},
+    (2, 5): {10: 1.13325e-3, 20: 1.38115e-4},
+}
+
+
+@pytest.mark.parametrize("k,r,N", [(k, r, N) for (k, r), d in INTERFACE.items() for N in d if N <= 20] + [(0, 4, 40), (2, 4, 40)])
+def test_interface_problem_energy_error_matches_xlsx(k, r, N):
+    """`cuthho_square -k K -M N -N N -r R -i` (run_cuthho_interface, cuthho_square.cpp:1625-1846):
+    make_hho_laplacian_interface, both cut stabilizations, the one-sided right-hand sides and the
+    interface_assembler with duplicated unknowns reproduce the 6 printed digits."""
+    err, msh = cd.run_interface(N, k, r)
+    ref = INTERFACE[(k, r)][N]
+    assert abs(err - ref) / ref < 6e-6, (err, ref)
+
+
+def test_interface_operator_properties(oracle):
+    """2rbs x 2rbs reconstruction of a cut cell: data symmetric positive semi-definite, constants
+    (the same on both sides) in its kernel, and kappa scaling of the one-sided blocks."""
+    m = oracle.CutMesh(10, refsteps=4)
+    di = oracle.degrees(2, 1)
+    cbs, fbs, ms = di.cbs, di.fbs, di.msize
+    u = np.zeros(2 * ms)
+    u[0] = u[cbs] = 1.0
+    u[2 * cbs::fbs] = 1.0
+    for c in np.nonzero(m.cell_loc == oracle.CUT_ON_INTERFACE)[0]:
+        st, oper, data = m.laplacian_interface(int(c), di)
+        assert st == 0 and oper.shape == (2 * di.rbs, 2 * ms) and data.shape == (2 * ms, 2 * ms)
+        scale = np.abs(data).max()
+        assert np.abs(data - data.T).max() < 1e-11 * scale
+        assert np.linalg.eigvalsh((data + data.T) / 2)[0] > -1e-9 * scale
+        assert np.abs(data @ u).max() < 1e-9 * scale
+    st, oper, data = m.laplacian_interface(0, di)
+    assert st != 0                                                          # "The cell is not cut" (:397-398)
+
+
 def test_cut_geometry_integrates_the_disc(oracle):
     """cuthho_square.cpp:681-732 (test_integration_domain): area and perimeter of the circle."""
     m = oracle.CutMesh(20, refsteps=4)
