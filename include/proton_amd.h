@@ -264,6 +264,45 @@ int pa_cut_local_ops_batch(pa_context *ctx, int face_deg, const pa_level_set *ls
 int pa_cut_merge(pa_context *ctx, int face_deg, int where, const double *d_cut_lc, const double *d_cut_rhs,
                  double *d_lc, double *d_rhs);
 
+/* ---- cutHHO two-sided interface problem (`cuthho_square -i`, run_cuthho_interface
+ * cuthho_square.cpp:1625-1846).  hho_degree_info(face_deg + 1, face_deg) (:1662). */
+typedef struct { double kappa_1, kappa_2, eta; } pa_interface_params;      /* params<T> :293-299: 1, 1, 5 */
+/* Cut cells, in ascending cell order.  Unknowns of a cut cell: [cell-, cell+, faces-, faces+]
+ * (2*msize).  d_oper ncut x (2rbs x 2msize) and d_data ncut x (2msize)^2: make_hho_laplacian_interface
+ * (:390-502); gr_lhs is semi-definite (the reference uses Eigen's pivoted LDLT): `oper` comes back
+ * with the constant of the negative side pinned to zero, `data` does not depend on that choice.
+ * d_lc ncut x (2msize)^2: data + kappa_1 * make_hho_cut_stabilization(NEGATIVE) + kappa_2 * (POSITIVE)
+ * scattered as :1694-1705.  d_rhs ncut x 2cbs: make_rhs(msh, cl, degree, where, f) of both sides
+ * (cuthho_utils.hpp:65-84, :1710-1711).  Any output may be NULL. */
+int pa_cut_interface_ops_batch(pa_context *ctx, int face_deg, const pa_level_set *ls, const pa_interface_params *parms,
+                               int rhs_fn, double *d_oper, double *d_data, double *d_lc, double *d_rhs, int32_t *d_info);
+/* Uncut cells (:1668-1681): d_lc ncells x msize^2 = kappa(side) * make_hho_laplacian.second +
+ * make_hho_naive_stabilization (fan quadrature), d_rhs ncells x cbs = make_rhs(f).  Rows of cut
+ * cells hold the uncut formulas too and are ignored by pa_interface_triplets_batch. */
+int pa_cut_interface_uncut_batch(pa_context *ctx, int face_deg, const pa_interface_params *parms, int rhs_fn,
+                                 double *d_lc, double *d_rhs, int32_t *d_info);
+/* interface_assembler (:1091-1443): sizes of the system with duplicated unknowns */
+typedef struct {
+    uint64_t num_all_cells;      /* cell blocks, cut cells counted twice              :1142-1150 */
+    uint64_t num_other_faces;    /* non-Dirichlet face blocks, cut faces counted twice :1152-1163 */
+    uint64_t system_size;        /* cbs * num_all_cells + fbs * num_other_faces        :1185      */
+    uint64_t ncut;
+} pa_interface_info;
+int pa_interface_assembler_query(pa_context *ctx, int face_deg, pa_interface_info *out);
+/* interface_assembler::assemble (:1203-1269) for the uncut cells and assemble_cut (:1271-1354)
+ * for the cut cells.  Uncut: d_rows/d_cols/d_vals ncells x msize^2 (slot i*msize + j; -1 for
+ * dropped slots and for every slot of a cut cell), d_rhs_rows/d_rhs_vals ncells x msize.  Cut:
+ * d_rows_cut/... ncut x (2msize)^2, d_rhs_rows_cut/d_rhs_vals_cut ncut x 2msize.  d_g: Dirichlet
+ * data (pa_dirichlet_data_batch) or NULL. */
+int pa_interface_triplets_batch(pa_context *ctx, int face_deg, const double *d_lc, const double *d_rhs, const double *d_g,
+                                const double *d_lc_cut, const double *d_rhs_cut,
+                                int32_t *d_rows, int32_t *d_cols, double *d_vals,
+                                int32_t *d_rows_cut, int32_t *d_cols_cut, double *d_vals_cut,
+                                int32_t *d_rhs_rows, double *d_rhs_vals, int32_t *d_rhs_rows_cut, double *d_rhs_vals_cut);
+/* cell dofs read back by interface_assembler::take_local_data (:1356-1379): d_offsets ncells x 2 =
+ * offset in the solution of the cell block of the negative / positive side (equal for uncut cells) */
+int pa_interface_cell_offsets(pa_context *ctx, int face_deg, int64_t *d_offsets);
+
 /* occupancy / launch facts of the dominant kernel for the roofline bookkeeping */
 typedef struct {
     int32_t lanes_per_cell, cells_per_block, block_threads, lds_bytes_per_block;

@@ -227,6 +227,49 @@ class BatchAssembler:
             self.ctx.cut_merge(fd, where, None, None, None, rhs.data_ptr())
         return out["lc"], rhs
 
+    # ---- cutHHO two-sided interface problem (cuthho_square -i) ------------------------------
+    def interface_local_ops(self, fd, kappa=(1.0, 1.0), eta=5.0, rhs_fn=capi.FN_SIN_SIN_RHS, want_oper=False):
+        """-> dict(lc, rhs: all cells, uncut formulas; lc_cut, rhs_cut [, oper_cut, data_cut]: cut cells)."""
+        parms = capi.InterfaceParams(kappa[0], kappa[1], eta)
+        cbs = (fd + 3) * (fd + 2) // 2
+        ms = cbs + 4 * (fd + 1)
+        n, nc = self.ncut, self.ncells
+        f64 = dict(dtype=torch.float64, device=self.device)
+        out = {"lc": torch.empty((nc, ms, ms), **f64), "rhs": torch.empty((nc, cbs), **f64),
+               "lc_cut": torch.empty((n, 2 * ms, 2 * ms), **f64), "rhs_cut": torch.empty((n, 2 * cbs), **f64),
+               "info_cut": torch.empty(n, dtype=torch.int32, device=self.device)}
+        if want_oper:
+            out["oper_cut"] = torch.empty((n, 2 * ms, 2 * cbs), **f64)
+            out["data_cut"] = torch.empty((n, 2 * ms, 2 * ms), **f64)
+        self.ctx.cut_interface_uncut(fd, parms, rhs_fn, out["lc"].data_ptr(), out["rhs"].data_ptr(), None)
+        self.ctx.cut_interface_ops(fd, self.level_set, parms, rhs_fn, _ptr(out.get("oper_cut")), _ptr(out.get("data_cut")),
+                                   out["lc_cut"].data_ptr(), out["rhs_cut"].data_ptr(), out["info_cut"].data_ptr())
+        return out
+
+    def interface_triplets(self, fd, ops, g=None):
+        """interface_assembler::assemble / assemble_cut -> dict of device arrays."""
+        cbs = (fd + 3) * (fd + 2) // 2
+        ms = cbs + 4 * (fd + 1)
+        n, nc = self.ncut, self.ncells
+        i32 = dict(dtype=torch.int32, device=self.device)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        t = {"rows": torch.empty((nc, ms * ms), **i32), "cols": torch.empty((nc, ms * ms), **i32), "vals": torch.empty((nc, ms * ms), **f64),
+             "rows_cut": torch.empty((n, 4 * ms * ms), **i32), "cols_cut": torch.empty((n, 4 * ms * ms), **i32),
+             "vals_cut": torch.empty((n, 4 * ms * ms), **f64),
+             "rhs_rows": torch.empty((nc, ms), **i32), "rhs_vals": torch.empty((nc, ms), **f64),
+             "rhs_rows_cut": torch.empty((n, 2 * ms), **i32), "rhs_vals_cut": torch.empty((n, 2 * ms), **f64)}
+        self.ctx.interface_triplets(fd, ops["lc"].data_ptr(), ops["rhs"].data_ptr(), _ptr(g), ops["lc_cut"].data_ptr(),
+                                    ops["rhs_cut"].data_ptr(), t["rows"].data_ptr(), t["cols"].data_ptr(), t["vals"].data_ptr(),
+                                    t["rows_cut"].data_ptr(), t["cols_cut"].data_ptr(), t["vals_cut"].data_ptr(),
+                                    t["rhs_rows"].data_ptr(), t["rhs_vals"].data_ptr(), t["rhs_rows_cut"].data_ptr(),
+                                    t["rhs_vals_cut"].data_ptr())
+        return t
+
+    def interface_cell_offsets(self, fd):
+        out = torch.empty((self.ncells, 2), dtype=torch.int64, device=self.device)
+        self.ctx.interface_cell_offsets(fd, out.data_ptr())
+        return out
+
     def synchronize(self):
         self.ctx.synchronize()
 
@@ -234,3 +277,4 @@ class BatchAssembler:
 def to_rowcol(t):
     """[n, cols, rows] device tensor of column-major matrices -> numpy [n, rows, cols]."""
     return t.detach().cpu().numpy().swapaxes(1, 2).copy()
+

@@ -29,6 +29,8 @@ EXPORTS = [
     "pa_obstacle_tables", "pa_obstacle_triplets_batch", "pa_obstacle_expand_solution",
     "pa_obstacle_take_local_data_batch",
     "pa_cut_preprocess", "pa_cut_query", "pa_cut_local_ops_batch", "pa_cut_merge",
+    "pa_cut_interface_ops_batch", "pa_cut_interface_uncut_batch", "pa_interface_assembler_query",
+    "pa_interface_triplets_batch", "pa_interface_cell_offsets",
 ]
 
 
@@ -39,6 +41,14 @@ class DegreeInfo(C.Structure):
 class Sizes(C.Structure):
     _fields_ = [("rbs", C.c_int32), ("cbs", C.c_int32), ("fbs", C.c_int32), ("msize", C.c_int32),
                 ("oper_rows", C.c_int32), ("cell_qps", C.c_int32), ("face_qps", C.c_int32)]
+
+
+class InterfaceParams(C.Structure):
+    _fields_ = [("kappa_1", C.c_double), ("kappa_2", C.c_double), ("eta", C.c_double)]
+
+
+class InterfaceInfo(C.Structure):
+    _fields_ = [("num_all_cells", C.c_uint64), ("num_other_faces", C.c_uint64), ("system_size", C.c_uint64), ("ncut", C.c_uint64)]
 
 
 class LaunchInfo(C.Structure):
@@ -126,6 +136,11 @@ def lib():
     L.pa_cut_query.argtypes = [vp, C.POINTER(sz), vp, vp]
     L.pa_cut_local_ops_batch.argtypes = [vp, C.c_int, C.POINTER(LevelSet), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp]
     L.pa_cut_merge.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp]
+    L.pa_cut_interface_ops_batch.argtypes = [vp, C.c_int, C.POINTER(LevelSet), C.POINTER(InterfaceParams), C.c_int, dp, dp, dp, dp, dp]
+    L.pa_cut_interface_uncut_batch.argtypes = [vp, C.c_int, C.POINTER(InterfaceParams), C.c_int, dp, dp, dp]
+    L.pa_interface_assembler_query.argtypes = [vp, C.c_int, C.POINTER(InterfaceInfo)]
+    L.pa_interface_triplets_batch.argtypes = [vp, C.c_int] + [dp] * 15
+    L.pa_interface_cell_offsets.argtypes = [vp, C.c_int, dp]
     _lib = L
     return L
 
@@ -261,6 +276,25 @@ class Context:
     def obstacle_take_local_data(self, di, first, n, expanded, out):
         self._ck(self._L.pa_obstacle_take_local_data_batch(self.h, di, first, n, expanded, out),
                  "pa_obstacle_take_local_data_batch")
+
+    def cut_interface_ops(self, face_deg, ls, parms, rhs_fn, oper, data, lc, rhs, info):
+        self._ck(self._L.pa_cut_interface_ops_batch(self.h, face_deg, C.byref(ls), C.byref(parms), rhs_fn, oper, data, lc, rhs, info),
+                 "pa_cut_interface_ops_batch")
+
+    def cut_interface_uncut(self, face_deg, parms, rhs_fn, lc, rhs, info):
+        self._ck(self._L.pa_cut_interface_uncut_batch(self.h, face_deg, C.byref(parms), rhs_fn, lc, rhs, info),
+                 "pa_cut_interface_uncut_batch")
+
+    def interface_info(self, face_deg):
+        out = InterfaceInfo()
+        self._ck(self._L.pa_interface_assembler_query(self.h, face_deg, C.byref(out)), "pa_interface_assembler_query")
+        return out
+
+    def interface_triplets(self, face_deg, *ptrs):
+        self._ck(self._L.pa_interface_triplets_batch(self.h, face_deg, *ptrs), "pa_interface_triplets_batch")
+
+    def interface_cell_offsets(self, face_deg, out):
+        self._ck(self._L.pa_interface_cell_offsets(self.h, face_deg, out), "pa_interface_cell_offsets")
 
     def cut_preprocess(self, Nx, Ny, ls, refsteps, lo=(0.0, 0.0), hi=(1.0, 1.0)):
         self._ck(self._L.pa_cut_preprocess(self.h, Nx, Ny, lo[0], hi[0], lo[1], hi[1], C.byref(ls), refsteps), "pa_cut_preprocess")

@@ -7,9 +7,11 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/proton_amd.h"
 #include "cut_device.hpp"
+#include "cut_interface_device.hpp"
 #include "cut_host.hpp"
 #include "hho_assembly.hpp"
 #include "hho_aux.hpp"
@@ -77,10 +79,13 @@ struct pa_context {
         uint32_t *co = nullptr, *io = nullptr, *ro = nullptr;
         double *cx = nullptr, *ix = nullptr, *rx = nullptr, *fl = nullptr, *fs = nullptr;
         int32_t *flc = nullptr, *fsc = nullptr;
-    } cl;
+    } cl[2];                                  // one slot per side (PA_LOC_NEGATIVE / PA_LOC_POSITIVE)
     uint32_t *d_cut_cells = nullptr;
-    int8_t *d_cell_loc = nullptr;
+    int8_t *d_cell_loc = nullptr, *d_face_loc = nullptr;
     int32_t *d_cut_index = nullptr;
+    // interface_assembler tables (cuthho_square.cpp:1137-1185)
+    int32_t *d_if_cell_table = nullptr, *d_if_face_table = nullptr;
+    size_t if_num_all_cells = 0, if_num_other_faces = 0;
     std::string last_error;
 };
 
@@ -103,9 +108,9 @@ static void release_faces(pa_context *ctx)
     ctx->nfaces_local = ctx->face_base = ctx->num_other_faces = 0;
 }
 
-static void release_cut_lists(pa_context *ctx)
+static void release_cut_lists(pa_context *ctx, int slot)
 {
-    auto &c = ctx->cl;
+    auto &c = ctx->cl[slot];
     (void)hipFree(c.co); (void)hipFree(c.io); (void)hipFree(c.ro); (void)hipFree(c.cx); (void)hipFree(c.ix);
     (void)hipFree(c.rx); (void)hipFree(c.fl); (void)hipFree(c.fs); (void)hipFree(c.flc); (void)hipFree(c.fsc);
     c = pa_context::CutListsDev();
@@ -113,12 +118,18 @@ static void release_cut_lists(pa_context *ctx)
 
 static void release_cut(pa_context *ctx)
 {
-    release_cut_lists(ctx);
+    release_cut_lists(ctx, 0);
+    release_cut_lists(ctx, 1);
     delete ctx->cut; ctx->cut = nullptr;
     if (ctx->d_cut_cells) (void)hipFree(ctx->d_cut_cells);
     if (ctx->d_cell_loc) (void)hipFree(ctx->d_cell_loc);
+    if (ctx->d_face_loc) (void)hipFree(ctx->d_face_loc);
     if (ctx->d_cut_index) (void)hipFree(ctx->d_cut_index);
-    ctx->d_cut_cells = nullptr; ctx->d_cell_loc = nullptr; ctx->d_cut_index = nullptr;
+    if (ctx->d_if_cell_table) (void)hipFree(ctx->d_if_cell_table);
+    if (ctx->d_if_face_table) (void)hipFree(ctx->d_if_face_table);
+    ctx->d_cut_cells = nullptr; ctx->d_cell_loc = nullptr; ctx->d_face_loc = nullptr; ctx->d_cut_index = nullptr;
+    ctx->d_if_cell_table = ctx->d_if_face_table = nullptr;
+    ctx->if_num_all_cells = ctx->if_num_other_faces = 0;
 }
 
 static void release_mesh(pa_context *ctx)
@@ -831,6 +842,27 @@ int pa_cut_preprocess(pa_context *ctx, size_t Nx, size_t Ny, double min_x, doubl
     PA_HIP(ctx, hipMemcpyAsync(ctx->d_cut_cells, cm->cut_cells.data(), ncut * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     PA_HIP(ctx, hipMemcpyAsync(ctx->d_cell_loc, cm->cell_loc.data(), nc, hipMemcpyHostToDevice, ctx->stream));
     PA_HIP(ctx, hipMemcpyAsync(ctx->d_cut_index, cm->cut_index.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    // interface_assembler tables (cuthho_square.cpp:1142-1178): cut cells / cut faces own two blocks
+    const size_t nf = cm->nfaces();
+    std::vector<int32_t> cell_table(nc), face_table(nf);
+    size_t blocks = 0;
+    for (size_t c = 0; c < nc; ++c) { cell_table[c] = (int32_t)blocks; blocks += cm->cell_loc[c] == pa::LOC_CUT ? 2 : 1; }
+    ctx->if_num_all_cells = blocks;
+    blocks = 0;
+    for (uint32_t f = 0; f < nf; ++f) {
+        uint32_t lo, hi; bool dirichlet; int32_t comp;
+        pa::sm_face_decode(cm->sm, f, lo, hi, dirichlet, comp);
+        if (dirichlet) { face_table[f] = -1; continue; }
+        face_table[f] = (int32_t)blocks;
+        blocks += cm->face_loc[f] == pa::LOC_CUT ? 2 : 1;
+    }
+    ctx->if_num_other_faces = blocks;
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_face_loc, nf));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_if_cell_table, nc * sizeof(int32_t)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_if_face_table, nf * sizeof(int32_t)));
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_face_loc, cm->face_loc.data(), nf, hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_if_cell_table, cell_table.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_if_face_table, face_table.data(), nf * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PA_OK;
 }
@@ -845,6 +877,38 @@ int pa_cut_query(pa_context *ctx, size_t *ncut, int8_t *cell_location, int32_t *
     return PA_OK;
 }
 
+// host list building + upload of the cut quadrature of one side: once per (face degree, side)
+static int ensure_cut_lists(pa_context *ctx, int face_deg, int where)
+{
+    if (ctx->cl[where].face_deg == face_deg && ctx->cl[where].where == where) return PA_OK;
+    pa::CutLists L;
+    try {
+        pa::build_cut_lists(*ctx->cut, ctx->host_tab, face_deg, where, L);
+    } catch (const std::invalid_argument &ex) {
+        ctx->last_error = ex.what();
+        return PA_ERR_QUADRATURE;
+    } catch (const std::exception &ex) {
+        ctx->last_error = ex.what();
+        return PA_ERR_INVALID_ARG;
+    }
+    release_cut_lists(ctx, where);
+    auto &c = ctx->cl[where];
+    hipError_t e = upload_vec(L.cell_off, &c.co, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.il_off, &c.io, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.ir_off, &c.ro, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.cell_xyw, &c.cx, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.il_xyw, &c.ix, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.ir_xyw, &c.rx, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.fl_xyw, &c.fl, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.fs_xyw, &c.fs, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.fl_cnt, &c.flc, ctx->stream);
+    if (e == hipSuccess) e = upload_vec(L.fs_cnt, &c.fsc, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // the host vectors go out of scope
+    if (e != hipSuccess) { ctx->last_error = std::string("cut lists upload: ") + hipGetErrorString(e); return PA_ERR_HIP; }
+    c.face_deg = face_deg; c.where = where;
+    return PA_OK;
+}
+
 int pa_cut_local_ops_batch(pa_context *ctx, int face_deg, const pa_level_set *ls, int where, int rhs_fn, int bcs_fn,
                            double *d_oper, double *d_data, double *d_stab, double *d_lc, double *d_rhs, int32_t *d_info)
 {
@@ -855,35 +919,11 @@ int pa_cut_local_ops_batch(pa_context *ctx, int face_deg, const pa_level_set *ls
     if (rhs_fn <= PA_FN_SAMPLED || rhs_fn > PA_FN_ONE || bcs_fn <= PA_FN_SAMPLED || bcs_fn > PA_FN_ONE) return PA_ERR_INVALID_ARG;
     const size_t ncut = ctx->cut->cut_cells.size();
     if (ncut == 0) return PA_OK;
+    int st = ensure_cut_lists(ctx, face_deg, where);
+    if (st != PA_OK) return st;
     hipError_t e = hipSuccess;
-    if (ctx->cl.face_deg != face_deg || ctx->cl.where != where) {     // host list building + upload: once
-        pa::CutLists L;
-        try {
-            pa::build_cut_lists(*ctx->cut, ctx->host_tab, face_deg, where, L);
-        } catch (const std::invalid_argument &ex) {
-            ctx->last_error = ex.what();
-            return PA_ERR_QUADRATURE;
-        } catch (const std::exception &ex) {
-            ctx->last_error = ex.what();
-            return PA_ERR_INVALID_ARG;
-        }
-        release_cut_lists(ctx);
-        auto &c = ctx->cl;
-        e = upload_vec(L.cell_off, &c.co, ctx->stream);
-        if (e == hipSuccess) e = upload_vec(L.il_off, &c.io, ctx->stream);
-        if (e == hipSuccess) e = upload_vec(L.ir_off, &c.ro, ctx->stream);
-        if (e == hipSuccess) e = upload_vec(L.cell_xyw, &c.cx, ctx->stream);
-        if (e == hipSuccess) e = upload_vec(L.il_xyw, &c.ix, ctx->stream);
-        if (e == hipSuccess) e = upload_vec(L.ir_xyw, &c.rx, ctx->stream);
-        if (e == hipSuccess) e = upload_vec(L.fl_xyw, &c.fl, ctx->stream);
-        if (e == hipSuccess) e = upload_vec(L.fs_xyw, &c.fs, ctx->stream);
-        if (e == hipSuccess) e = upload_vec(L.fl_cnt, &c.flc, ctx->stream);
-        if (e == hipSuccess) e = upload_vec(L.fs_cnt, &c.fsc, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // the host vectors go out of scope
-        if (e == hipSuccess) { c.face_deg = face_deg; c.where = where; }
-    }
-    if (e == hipSuccess) {
-        const auto &c = ctx->cl;
+    {
+        const auto &c = ctx->cl[where];
         pa::CutArgs a;
         a.tab = ctx->d_tab; a.points = ctx->d_points; a.ptids = ctx->d_ptids; a.cut_cells = ctx->d_cut_cells;
         a.ncut = (uint32_t)ncut;
@@ -915,6 +955,172 @@ int pa_cut_merge(pa_context *ctx, int face_deg, int where, const double *d_cut_l
     hipLaunchKernelGGL(pa::cut_merge_kernel, dim3(grid), dim3(64), 0, ctx->stream, nc, ctx->d_cell_loc, ctx->d_cut_index, where,
                        ms * ms, cbs, d_cut_lc, d_cut_rhs, d_lc, d_rhs);
     PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
+// ---- two-sided interface problem -------------------------------------------------------------
+static int interface_checks(pa_context *ctx, int face_deg)
+{
+    if (!ctx) return PA_ERR_INVALID_ARG;
+    if (!ctx->cut) return PA_ERR_NO_MESH;
+    if (face_deg < 0) return PA_ERR_INVALID_DEGREE;
+    if (face_deg > 2) return PA_ERR_QUADRATURE;            // 2*recdeg = 8 selects the empty rules[8]
+    return PA_OK;
+}
+
+int pa_cut_interface_ops_batch(pa_context *ctx, int face_deg, const pa_level_set *ls, const pa_interface_params *parms,
+                               int rhs_fn, double *d_oper, double *d_data, double *d_lc, double *d_rhs, int32_t *d_info)
+{
+    int st = interface_checks(ctx, face_deg);
+    if (st != PA_OK) return st;
+    if (!ls || !parms || rhs_fn <= PA_FN_SAMPLED || rhs_fn > PA_FN_ONE) return PA_ERR_INVALID_ARG;
+    const size_t ncut = ctx->cut->cut_cells.size();
+    if (ncut == 0) return PA_OK;
+    for (int side = 0; side < 2; ++side) {
+        st = ensure_cut_lists(ctx, face_deg, side);
+        if (st != PA_OK) return st;
+    }
+    const int cbs = pa::P2(face_deg + 1), nfd = 4 * (face_deg + 1), ms = cbs + nfd, m2 = 2 * ms;
+    double *scratch = nullptr;                              // [data | stab_n | stab_p] when lc is requested
+    double *data = d_data, *stab_n = nullptr, *stab_p = nullptr;
+    if (d_lc) {
+        const size_t need = (d_data ? 0 : ncut * (size_t)m2 * m2) + 2 * ncut * (size_t)ms * ms;
+        PA_HIP(ctx, hipMalloc((void **)&scratch, need * sizeof(double)));
+        double *p = scratch;
+        if (!d_data) { data = p; p += ncut * (size_t)m2 * m2; }
+        stab_n = p; stab_p = p + ncut * (size_t)ms * ms;
+        // make_hho_cut_stabilization of both sides through the fictitious-domain kernel
+        st = pa_cut_local_ops_batch(ctx, face_deg, ls, PA_LOC_NEGATIVE, PA_FN_ONE, PA_FN_ONE, nullptr, nullptr, stab_n, nullptr, nullptr, nullptr);
+        if (st == PA_OK)
+            st = pa_cut_local_ops_batch(ctx, face_deg, ls, PA_LOC_POSITIVE, PA_FN_ONE, PA_FN_ONE, nullptr, nullptr, stab_p, nullptr, nullptr, nullptr);
+        if (st != PA_OK) { (void)hipFree(scratch); return st; }
+    }
+    pa::CutInterfaceArgs a;
+    a.points = ctx->d_points; a.ptids = ctx->d_ptids; a.cut_cells = ctx->d_cut_cells; a.ncut = (uint32_t)ncut;
+    for (int side = 0; side < 2; ++side) {
+        a.cell_off[side] = ctx->cl[side].co; a.cell_xyw[side] = ctx->cl[side].cx;
+        a.fl_xyw[side] = ctx->cl[side].fl; a.fl_cnt[side] = ctx->cl[side].flc;
+    }
+    a.il_off = ctx->cl[0].io; a.il_xyw = ctx->cl[0].ix;     // integrate_interface(.., IN_NEGATIVE_SIDE) (:437)
+    a.ls = pa::LevelSet{ls->kind, ls->radius, ls->alpha, ls->beta, ls->cut_y};
+    a.rhs_fn = rhs_fn; a.kappa[0] = parms->kappa_1; a.kappa[1] = parms->kappa_2; a.eta = parms->eta;
+    a.oper = d_oper; a.data = data; a.rhs = d_rhs; a.info = d_info;
+    const int grid = (int)(ncut < (size_t)ctx->num_cus * 2 ? ncut : (size_t)ctx->num_cus * 2);
+    switch (face_deg) {
+    case 0: hipLaunchKernelGGL((pa::cut_interface_kernel<0>), dim3(grid), dim3(64), 0, ctx->stream, a); break;
+    case 1: hipLaunchKernelGGL((pa::cut_interface_kernel<1>), dim3(grid), dim3(64), 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL((pa::cut_interface_kernel<2>), dim3(grid), dim3(64), 0, ctx->stream, a); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && d_lc) {
+        hipLaunchKernelGGL(pa::cut_interface_lc_kernel, dim3(grid), dim3(256), 0, ctx->stream, (uint32_t)ncut, cbs, nfd,
+                           parms->kappa_1, parms->kappa_2, data, stab_n, stab_p, d_lc);
+        e = hipGetLastError();
+    }
+    if (scratch) {
+        const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(scratch);
+        if (e == hipSuccess) e = e2;
+    }
+    if (e != hipSuccess) { ctx->last_error = std::string("pa_cut_interface_ops_batch: ") + hipGetErrorString(e); return PA_ERR_HIP; }
+    return PA_OK;
+}
+
+int pa_cut_interface_uncut_batch(pa_context *ctx, int face_deg, const pa_interface_params *parms, int rhs_fn, double *d_lc,
+                                 double *d_rhs, int32_t *d_info)
+{
+    int st = interface_checks(ctx, face_deg);
+    if (st != PA_OK) return st;
+    if (!parms || (d_rhs && (rhs_fn <= PA_FN_SAMPLED || rhs_fn > PA_FN_ONE))) return PA_ERR_INVALID_ARG;
+    const pa_degree_info di = {face_deg + 1, face_deg, face_deg + 1};
+    const size_t n = ctx->ncells;
+    const int ms = pa::P2(face_deg + 1) + 4 * (face_deg + 1), mm = ms * ms;
+    if (d_lc) {
+        if (parms->kappa_1 == 1.0 && parms->kappa_2 == 1.0) {
+            st = pa_local_ops_batch(ctx, di, PA_QUAD_FAN, PA_STAB_NAIVE, 0, n, nullptr, nullptr, nullptr, d_lc, d_info);
+            if (st != PA_OK) return st;
+        } else {
+            double *scratch = nullptr;
+            PA_HIP(ctx, hipMalloc((void **)&scratch, 2 * n * (size_t)mm * sizeof(double)));
+            st = pa_local_ops_batch(ctx, di, PA_QUAD_FAN, PA_STAB_NAIVE, 0, n, nullptr, scratch, scratch + n * (size_t)mm, nullptr, d_info);
+            hipError_t e = hipSuccess;
+            if (st == PA_OK) {
+                const size_t total = n * (size_t)mm;
+                hipLaunchKernelGGL(pa::cut_interface_uncut_lc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, n, mm,
+                                   ctx->d_cell_loc, parms->kappa_1, parms->kappa_2, scratch, scratch + n * (size_t)mm, d_lc);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            }
+            (void)hipFree(scratch);
+            if (st != PA_OK) return st;
+            PA_HIP(ctx, e);
+        }
+    }
+    if (d_rhs) {
+        st = pa_cell_rhs_batch(ctx, face_deg + 1, 0, PA_QUAD_FAN, rhs_fn, nullptr, 0, n, d_rhs);
+        if (st != PA_OK) return st;
+    }
+    return PA_OK;
+}
+
+int pa_interface_assembler_query(pa_context *ctx, int face_deg, pa_interface_info *out)
+{
+    if (!ctx || !out || face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_ARG;
+    if (!ctx->cut) return PA_ERR_NO_MESH;
+    out->num_all_cells = ctx->if_num_all_cells;
+    out->num_other_faces = ctx->if_num_other_faces;
+    out->system_size = (uint64_t)pa::P2(face_deg + 1) * ctx->if_num_all_cells + (uint64_t)(face_deg + 1) * ctx->if_num_other_faces;
+    out->ncut = ctx->cut->cut_cells.size();
+    return PA_OK;
+}
+
+int pa_interface_triplets_batch(pa_context *ctx, int face_deg, const double *d_lc, const double *d_rhs, const double *d_g,
+                                const double *d_lc_cut, const double *d_rhs_cut, int32_t *d_rows, int32_t *d_cols,
+                                double *d_vals, int32_t *d_rows_cut, int32_t *d_cols_cut, double *d_vals_cut,
+                                int32_t *d_rhs_rows, double *d_rhs_vals, int32_t *d_rhs_rows_cut, double *d_rhs_vals_cut)
+{
+    if (!ctx || !d_lc || !d_rows || !d_cols || !d_vals || !d_rhs_rows || !d_rhs_vals) return PA_ERR_INVALID_ARG;
+    if (face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_DEGREE;
+    if (!ctx->cut || !ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    const size_t ncut = ctx->cut->cut_cells.size();
+    if (ncut && (!d_lc_cut || !d_rows_cut || !d_cols_cut || !d_vals_cut || !d_rhs_rows_cut || !d_rhs_vals_cut)) return PA_ERR_INVALID_ARG;
+    pa_interface_info info;
+    pa_interface_assembler_query(ctx, face_deg, &info);
+    if (info.system_size >= ((uint64_t)1 << 31)) return PA_ERR_INVALID_ARG;      // Eigen::Triplet stores int indices
+    pa::InterfaceTripletArgs a;
+    a.cell_faces = ctx->d_cell_faces; a.cell_loc = ctx->d_cell_loc; a.face_loc = ctx->d_face_loc; a.cut_index = ctx->d_cut_index;
+    a.cell_table = ctx->d_if_cell_table; a.face_table = ctx->d_if_face_table; a.g = d_g;
+    a.lc = d_lc; a.rhs = d_rhs; a.lc_cut = d_lc_cut; a.rhs_cut = d_rhs_cut;
+    a.ncells = ctx->ncells; a.num_all_cells = ctx->if_num_all_cells;
+    a.cbs = pa::P2(face_deg + 1); a.fbs = face_deg + 1;
+    a.rows = d_rows; a.cols = d_cols; a.vals = d_vals; a.rows_cut = d_rows_cut; a.cols_cut = d_cols_cut; a.vals_cut = d_vals_cut;
+    a.rhs_rows = d_rhs_rows; a.rhs_vals = d_rhs_vals; a.rhs_rows_cut = d_rhs_rows_cut; a.rhs_vals_cut = d_rhs_vals_cut;
+    const int m2 = 2 * (a.cbs + 4 * a.fbs);
+    const size_t shmem = m2 * sizeof(double) + m2 * sizeof(int32_t);
+    const size_t resident = (size_t)ctx->num_cus * 8;
+    const int grid = (int)(ctx->ncells < resident ? ctx->ncells : resident);
+    hipLaunchKernelGGL(pa::interface_triplets_kernel, dim3(grid), dim3(256), shmem, ctx->stream, a);
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
+int pa_interface_cell_offsets(pa_context *ctx, int face_deg, int64_t *d_offsets)
+{
+    if (!ctx || !d_offsets || face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_ARG;
+    if (!ctx->cut) return PA_ERR_NO_MESH;
+    const pa::CutMeshHost &cm = *ctx->cut;
+    const size_t nc = cm.ncells();
+    const int64_t cbs = pa::P2(face_deg + 1);
+    std::vector<int64_t> off(2 * nc);
+    int64_t blocks = 0;
+    for (size_t c = 0; c < nc; ++c) {                      // :1368-1379
+        const bool cut = cm.cell_loc[c] == pa::LOC_CUT;
+        off[2 * c] = blocks * cbs;
+        off[2 * c + 1] = cut ? (blocks + 1) * cbs : blocks * cbs;
+        blocks += cut ? 2 : 1;
+    }
+    PA_HIP(ctx, hipMemcpyAsync(d_offsets, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PA_OK;
 }
 
