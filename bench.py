@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--workload", default="quad1024_k2", choices=sorted(WORKLOADS))
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "none"],
                     help="N>1 only: all_gather of the condensed face-dof blocks at the end of every step")
+    ap.add_argument("--backend", default=os.environ.get("PA_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="nccl = RCCL, one rank per GPU (what the driver runs); gloo = rehearsal of the N>1 code path with "
+                         "several ranks sharing the visible GPU(s) and a host-staged exchange (numbers not comparable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="cell rows timed by the CPU baseline (0 = auto, ~15 s)")
     args = ap.parse_args()
@@ -131,10 +134,16 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    rehearsal = world > 1 and args.backend == "gloo"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     w = WORKLOADS[args.workload]
     N = w["N"]
@@ -160,7 +169,7 @@ def main():
     exchange = world > 1 and args.exchange == "allgather"
     if exchange:
         nf = 4 * sz.fbs
-        ex = CondensedExchange(cell_counts(N, N, world), condensed_per_cell(sz.fbs), rank, dev)
+        ex = CondensedExchange(cell_counts(N, N, world), condensed_per_cell(sz.fbs), rank, dev, host_staged=rehearsal)
         S_view, g_view = ex.local_S_g(nf)
 
     if cut:
@@ -202,7 +211,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kern_ms = sum(a.elapsed_time(b) for a, b in zip(k_start, k_stop)) / args.steps
-    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(t[0]), float(t[1])
@@ -211,6 +220,12 @@ def main():
     probe = lc[:: max(1, n_local // 64)]
     if not os.environ.get("PA_ABLATE"):      # (profiling-only stage ablation produces garbage on purpose)
         assert bool(torch.isfinite(probe).all()) and float(probe.abs().max()) > 0.0
+
+    if exchange:                             # every rank's condensed blocks arrived (finite, non-trivial)
+        for r in range(world):
+            Sg, gg = ex.gathered_S_g(r, 4 * sz.fbs)
+            pr = Sg[:: max(1, Sg.shape[0] // 16)]
+            assert bool(torch.isfinite(pr).all()) and float(pr.abs().max()) > 0.0, "gathered block of rank %d" % r
 
     if rank == 0:
         total_cells = N * N
@@ -238,7 +253,8 @@ def main():
                        "hho_degree_info": [w["cd"], w["fd"]], "k": w["fd"], "quadrature": w["quad"], "stabilization": w["stab"],
                        "cells": total_cells, "msize": sz.msize, "outputs": "lc (msize^2 f64) + cell rhs per cell, to HBM",
                        "parallelism": "cell rows block-partitioned over %d GPU(s)" % world,
-                       "exchange": ("static condensation + RCCL all_gather of condensed face blocks (values)" if exchange else "none"),
+                       "exchange": (("static condensation + %s all_gather of condensed face blocks (values)"
+                                     % ("host-staged gloo (REHEARSAL, not RCCL)" if rehearsal else "RCCL")) if exchange else "none"),
                        "note": w["note"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -24,12 +24,18 @@ class CondensedExchange:
     """Preallocated buffers for the per-step all_gather; ranks may own different numbers of cells
     (the send buffer is padded to the largest block, the result is compacted by views)."""
 
-    def __init__(self, counts, per_cell, rank, device, dtype=torch.float64):
+    def __init__(self, counts, per_cell, rank, device, dtype=torch.float64, host_staged=False):
         self.counts, self.per_cell, self.rank = list(counts), per_cell, rank
         self.world = len(counts)
         self.slot = max(counts) * per_cell
         self.send = torch.zeros(self.slot, dtype=dtype, device=device)
         self.recv = torch.empty(self.world * self.slot, dtype=dtype, device=device)
+        # rehearsal mode (several ranks on ONE GPU cannot form an RCCL communicator): the collective
+        # runs on host copies through gloo; the device buffers and their layout are the same
+        self.host_staged = host_staged and self.send.is_cuda
+        if self.host_staged:
+            self.h_send = torch.empty(self.slot, dtype=dtype).pin_memory()
+            self.h_recv = torch.empty(self.world * self.slot, dtype=dtype).pin_memory()
 
     def local_view(self):
         """where this rank writes its n_local * per_cell values before exchange()"""
@@ -49,6 +55,10 @@ class CondensedExchange:
     def exchange(self):
         if self.world == 1:
             self.recv[: self.slot].copy_(self.send)
+        elif self.host_staged:
+            self.h_send.copy_(self.send)                   # synchronizes with the producing stream
+            dist.all_gather_into_tensor(self.h_recv, self.h_send)
+            self.recv.copy_(self.h_recv, non_blocking=True)
         else:
             dist.all_gather_into_tensor(self.recv, self.send)
         return self.recv
