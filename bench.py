@@ -169,7 +169,7 @@ def main():
     exchange = world > 1 and args.exchange == "allgather"
     if exchange:
         nf = 4 * sz.fbs
-        ex = CondensedExchange(cell_counts(N, N, world), condensed_per_cell(sz.fbs), rank, dev, host_staged=rehearsal)
+        ex = CondensedExchange(cell_counts(N, N, world), condensed_per_cell(sz.fbs, packed=True), rank, dev, host_staged=rehearsal)
         S_view, g_view = ex.local_S_g(nf)
 
     if cut:
@@ -191,8 +191,7 @@ def main():
                                   cut_lc.data_ptr(), cut_rhs.data_ptr(), None)
             asm.ctx.cut_merge(w["fd"], pa.capi.LOC_NEGATIVE, cut_lc.data_ptr(), cut_rhs.data_ptr(), lc.data_ptr(), rhs.data_ptr())
         if exchange:
-            asm.ctx.static_condensation(di, n_local, lc.data_ptr(), rhs.data_ptr(), S_view.data_ptr(), g_view.data_ptr(),
-                                        None, None)
+            asm.ctx.static_condensation_packed(di, n_local, lc.data_ptr(), rhs.data_ptr(), S_view.data_ptr(), g_view.data_ptr(), None)
             ex.exchange()
 
     for _ in range(args.warmup):
@@ -253,7 +252,7 @@ def main():
                        "hho_degree_info": [w["cd"], w["fd"]], "k": w["fd"], "quadrature": w["quad"], "stabilization": w["stab"],
                        "cells": total_cells, "msize": sz.msize, "outputs": "lc (msize^2 f64) + cell rhs per cell, to HBM",
                        "parallelism": "cell rows block-partitioned over %d GPU(s)" % world,
-                       "exchange": (("static condensation + %s all_gather of condensed face blocks (values)"
+                       "exchange": (("static condensation + %s all_gather of the condensed face blocks (upper triangles, values only)"
                                      % ("host-staged gloo (REHEARSAL, not RCCL)" if rehearsal else "RCCL")) if exchange else "none"),
                        "note": w["note"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -143,6 +143,12 @@ int pa_cell_quadrature_points(pa_context *ctx, int degree, int quad_kind,
 int pa_static_condensation_batch(pa_context *ctx, pa_degree_info di, size_t n,
                                  const double *d_lc, const double *d_rhs,
                                  double *d_S, double *d_g, double *d_rec, int32_t *d_info);
+/* Same, with the symmetric Schur complement stored as its upper triangle, column-packed:
+ * d_Sp[c][j*(j+1)/2 + i] = S(i,j), i <= j, nf*(nf+1)/2 values per cell (the multi-GPU exchange
+ * format: values only, indices closed-form). */
+int pa_static_condensation_packed_batch(pa_context *ctx, pa_degree_info di, size_t n,
+                                        const double *d_lc, const double *d_rhs,
+                                        double *d_Sp, double *d_g, int32_t *d_info);
 
 /* ---- assembler<Mesh> (hho.hpp:252-463) ---------------------------------------------------
  * Face connectivity.  pa_mesh_generate builds it in closed form; for an uploaded mesh supply

@@ -23,7 +23,7 @@ EXPORTS = [
     "pa_malloc", "pa_free", "pa_memcpy_h2d", "pa_memcpy_d2h", "pa_memset",
     "pa_mesh_upload", "pa_mesh_attach_device", "pa_mesh_generate", "pa_mesh_counts",
     "pa_local_ops_batch", "pa_cell_rhs_batch", "pa_cell_quadrature_points",
-    "pa_static_condensation_batch", "pa_local_ops_launch_info",
+    "pa_static_condensation_batch", "pa_static_condensation_packed_batch", "pa_local_ops_launch_info",
     "pa_mesh_set_faces", "pa_assembler_query", "pa_dirichlet_data_batch", "pa_face_quadrature_points",
     "pa_triplets_batch", "pa_take_local_data_batch", "pa_project_function_batch", "pa_energy_form_batch",
     "pa_obstacle_tables", "pa_obstacle_triplets_batch", "pa_obstacle_expand_solution",
@@ -119,6 +119,7 @@ def lib():
     L.pa_cell_rhs_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp, sz, sz, dp]
     L.pa_cell_quadrature_points.argtypes = [vp, C.c_int, C.c_int, sz, sz, dp, C.POINTER(C.c_int32)]
     L.pa_static_condensation_batch.argtypes = [vp, DegreeInfo, sz, dp, dp, dp, dp, dp, dp]
+    L.pa_static_condensation_packed_batch.argtypes = [vp, DegreeInfo, sz, dp, dp, dp, dp, dp]
     L.pa_local_ops_launch_info.argtypes = [vp, DegreeInfo, C.c_int, C.c_int, sz, C.POINTER(LaunchInfo)]
     L.pa_mesh_set_faces.argtypes = [vp, vp, vp, vp, sz]
     L.pa_assembler_query.argtypes = [vp, DegreeInfo, C.POINTER(AssemblerInfo)]
@@ -222,6 +223,10 @@ class Context:
         self._ck(self._L.pa_cell_quadrature_points(self.h, degree, quad, first, n, xyw, C.byref(nq)),
                  "pa_cell_quadrature_points")
         return nq.value
+
+    def static_condensation_packed(self, di, n, lc, rhs=None, Sp=None, g=None, info=None):
+        self._ck(self._L.pa_static_condensation_packed_batch(self.h, di, n, lc, rhs, Sp, g, info),
+                 "pa_static_condensation_packed_batch")
 
     def static_condensation(self, di, n, lc, rhs=None, S=None, g=None, rec=None, info=None):
         self._ck(self._L.pa_static_condensation_batch(self.h, di, n, lc, rhs, S, g, rec, info),

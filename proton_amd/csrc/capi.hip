@@ -792,8 +792,23 @@ int pa_cell_quadrature_points(pa_context *ctx, int degree, int quad_kind, size_t
 }
 
 // ---- static condensation -------------------------------------------------------------------
+static int condense(pa_context *ctx, pa_degree_info di, size_t n, const double *d_lc, const double *d_rhs, double *d_S,
+                    double *d_g, double *d_rec, int32_t *d_info, int packed);
+
 int pa_static_condensation_batch(pa_context *ctx, pa_degree_info di, size_t n, const double *d_lc, const double *d_rhs,
                                  double *d_S, double *d_g, double *d_rec, int32_t *d_info)
+{
+    return condense(ctx, di, n, d_lc, d_rhs, d_S, d_g, d_rec, d_info, 0);
+}
+
+int pa_static_condensation_packed_batch(pa_context *ctx, pa_degree_info di, size_t n, const double *d_lc,
+                                        const double *d_rhs, double *d_Sp, double *d_g, int32_t *d_info)
+{
+    return condense(ctx, di, n, d_lc, d_rhs, d_Sp, d_g, nullptr, d_info, 1);
+}
+
+static int condense(pa_context *ctx, pa_degree_info di, size_t n, const double *d_lc, const double *d_rhs, double *d_S,
+                    double *d_g, double *d_rec, int32_t *d_info, int packed)
 {
     if (!ctx || !d_lc) return PA_ERR_INVALID_ARG;
     pa_sizes sz;
@@ -805,7 +820,7 @@ int pa_static_condensation_batch(pa_context *ctx, pa_degree_info di, size_t n, c
 #define PA_SC_CASE(CD, FD)                                                                                    \
     if (di.cell_deg == CD && di.face_deg == FD) {                                                             \
         hipLaunchKernelGGL((pa::static_condensation_kernel<pa::P2(CD), 4 * (FD + 1)>), dim3(grid), dim3(64), 0, \
-                           ctx->stream, n, d_lc, d_rhs, d_S, d_g, d_rec, d_info);                             \
+                           ctx->stream, n, d_lc, d_rhs, d_S, d_g, d_rec, d_info, packed);                     \
         PA_HIP(ctx, hipGetLastError());                                                                       \
         return PA_OK;                                                                                         \
     }

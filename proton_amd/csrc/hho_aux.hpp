@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void cell_project_kernel(const QuadTables *tab
 template <int CBS, int NF>
 __global__ __launch_bounds__(64) void static_condensation_kernel(size_t n, const double *lc, const double *rhs,
                                                                  double *Sout, double *gout, double *recout,
-                                                                 int32_t *info)
+                                                                 int32_t *info, int packed)
 {
     constexpr int MS = CBS + NF, G = 64;
     static_assert(NF + 1 <= G && CBS <= G, "one lane per column");
@@ -297,9 +297,11 @@ __global__ __launch_bounds__(64) void static_condensation_kernel(size_t n, const
         if (Sout != nullptr)
             for (int e = l; e < NF * NF; e += G) {
                 const int i = e % NF, j = e / NF;
+                if (packed && i > j) continue;                     // S is symmetric: upper triangle, column-packed
                 double s = A[(CBS + i) + (CBS + j) * MS];
                 for (int k = 0; k < CBS; ++k) s += A[(CBS + i) + k * MS] * REC[k + (1 + j) * CBS];
-                Sout[cell * (size_t)(NF * NF) + e] = s;
+                if (packed) Sout[cell * (size_t)(NF * (NF + 1) / 2) + j * (j + 1) / 2 + i] = s;
+                else Sout[cell * (size_t)(NF * NF) + e] = s;
             }
         if (gout != nullptr && l < NF) {
             double s = 0.0;

@@ -14,10 +14,21 @@ def cell_counts(Nx, Ny, world):
     return [(row_partition(Ny, world, r)[1] - row_partition(Ny, world, r)[0]) * Nx for r in range(world)]
 
 
-def condensed_per_cell(fbs):
-    """values exchanged per cell: S (4 fbs)^2 (values only, indices are closed-form) + g (4 fbs)"""
+def condensed_per_cell(fbs, packed=False):
+    """values exchanged per cell: S (4 fbs)^2 -- or its upper triangle when packed -- plus g (4 fbs);
+    values only, the indices are closed-form"""
     nf = 4 * fbs
-    return nf * nf + nf
+    return (nf * (nf + 1) // 2 if packed else nf * nf) + nf
+
+
+def unpack_symmetric(Sp, nf):
+    """[n, nf(nf+1)/2] column-packed upper triangles -> [n, nf, nf] symmetric matrices"""
+    iu = torch.triu_indices(nf, nf, device=Sp.device)          # row-major pairs (i <= j)
+    pos = iu[1] * (iu[1] + 1) // 2 + iu[0]
+    S = torch.zeros((Sp.shape[0], nf, nf), dtype=Sp.dtype, device=Sp.device)
+    S[:, iu[0], iu[1]] = Sp[:, pos]
+    S[:, iu[1], iu[0]] = Sp[:, pos]
+    return S
 
 
 class CondensedExchange:
@@ -41,16 +52,19 @@ class CondensedExchange:
         """where this rank writes its n_local * per_cell values before exchange()"""
         return self.send[: self.counts[self.rank] * self.per_cell]
 
+    def _split(self, v, n, nf):
+        ns = self.per_cell - nf                            # nf*nf, or nf(nf+1)/2 when packed
+        S = v[: n * ns]
+        return (S.view(n, nf, nf) if ns == nf * nf else S.view(n, ns)), v[n * ns:].view(n, nf)
+
     def local_S_g(self, nf):
-        """the layout the condensation kernel writes: all S blocks [n, nf, nf], then all g [n, nf]"""
-        n = self.counts[self.rank]
-        v = self.local_view()
-        return v[: n * nf * nf].view(n, nf, nf), v[n * nf * nf:].view(n, nf)
+        """the layout the condensation kernel writes: all S blocks ([n, nf, nf], or [n, nf(nf+1)/2]
+        packed upper triangles), then all g [n, nf]"""
+        return self._split(self.local_view(), self.counts[self.rank], nf)
 
     def gathered_S_g(self, r, nf):
         n = self.counts[r]
-        v = self.recv[r * self.slot: r * self.slot + n * self.per_cell]
-        return v[: n * nf * nf].view(n, nf, nf), v[n * nf * nf:].view(n, nf)
+        return self._split(self.recv[r * self.slot: r * self.slot + n * self.per_cell], n, nf)
 
     def exchange(self):
         if self.world == 1:

@@ -90,6 +90,17 @@ def test_matches_golden(asm, cname, cd, fd, kind):
         assert int(info.cpu()[0]) == 0
         assert nerr(S.cpu().numpy()[0].T, g("S")) < 10 * TOL
         assert np.abs(gg.cpu().numpy()[0] - g("g")[:, 0]).max() < 10 * TOL * max(np.abs(g("g")).max(), np.abs(g("rhs")).max())
+        # packed upper triangle (the multi-GPU exchange format) carries the same values
+        import torch
+        from proton_amd.partition import unpack_symmetric
+        nf = S.shape[1]
+        Sp = torch.empty((S.shape[0], nf * (nf + 1) // 2), dtype=torch.float64, device=S.device)
+        g2 = torch.empty_like(gg)
+        di_, _ = pa.degree_info(cd, fd)
+        asm.ctx.static_condensation_packed(di_, S.shape[0], out["lc"].data_ptr(), rhs.data_ptr(), Sp.data_ptr(), g2.data_ptr(), None)
+        U = unpack_symmetric(Sp, nf)
+        iu = torch.triu_indices(nf, nf)
+        assert torch.equal(U[:, iu[0], iu[1]], S[:, iu[1], iu[0]]) and torch.equal(g2, gg)      # S[c, j, i] = S(i, j)
 
 
 def perturbed_mesh(oracle, N, seed, lo=(0.0, 0.0), hi=(1.0, 1.0)):

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from proton_amd.partition import CondensedExchange, cell_counts, condensed_per_cell, row_partition
+from proton_amd.partition import CondensedExchange, cell_counts, condensed_per_cell, row_partition, unpack_symmetric
 
 
 def test_row_partition_covers_all_rows():
@@ -39,40 +39,49 @@ def _condensed_blocks(N, cd, fd, first, n):
     return Sb, gb
 
 
-def _worker(rank, world, port, N, cd, fd, q):
+def _worker(rank, world, port, N, cd, fd, q, packed=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import oracle_lib as o
         di = o.degrees(cd, fd)
-        per = condensed_per_cell(di.fbs)
+        per = condensed_per_cell(di.fbs, packed)
         counts = cell_counts(N, N, world)
         r0, r1 = row_partition(N, world, rank)
         ex = CondensedExchange(counts, per, rank, torch.device("cpu"))
         nf = 4 * di.fbs
         Sb, gb = _condensed_blocks(N, cd, fd, r0 * N, (r1 - r0) * N)
         S_view, g_view = ex.local_S_g(nf)
-        S_view.copy_(torch.from_numpy(Sb))
+        if packed:                                   # upper triangle, column-packed: the bench's exchange format
+            iu = np.triu_indices(nf)
+            Sp = np.zeros((Sb.shape[0], nf * (nf + 1) // 2))
+            Sp[:, iu[1] * (iu[1] + 1) // 2 + iu[0]] = Sb[:, iu[1], iu[0]]      # Sb is column-major: Sb[c, j, i] = S(i, j)
+            S_view.copy_(torch.from_numpy(Sp))
+        else:
+            S_view.copy_(torch.from_numpy(Sb))
         g_view.copy_(torch.from_numpy(gb))
         dist.barrier()
         ex.exchange()
-        fullS = torch.cat([ex.gathered_S_g(r, nf)[0] for r in range(world)], dim=0).numpy()
+        parts = [ex.gathered_S_g(r, nf)[0] for r in range(world)]
+        if packed:
+            parts = [unpack_symmetric(p_, nf) for p_ in parts]
+        fullS = torch.cat(parts, dim=0).numpy()
         fullg = torch.cat([ex.gathered_S_g(r, nf)[1] for r in range(world)], dim=0).numpy()
         q.put((rank, (fullS, fullg)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N,cd,fd", [(6, 2, 1), (5, 3, 2)])
-def test_two_rank_exchange_matches_single_process(N, cd, fd):
+@pytest.mark.parametrize("N,cd,fd,packed", [(6, 2, 1, False), (5, 3, 2, False), (5, 3, 2, True), (7, 0, 1, True)])
+def test_two_rank_exchange_matches_single_process(N, cd, fd, packed):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     world = 2
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, cd, fd, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, cd, fd, q, packed)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=120) for _ in range(world))
@@ -80,6 +89,11 @@ def test_two_rank_exchange_matches_single_process(N, cd, fd):
         p.join(timeout=60)
         assert p.exitcode == 0
     refS, refg = _condensed_blocks(N, cd, fd, 0, N * N)
+    iu = np.triu_indices(refS.shape[1])
     for r in range(world):
-        assert np.array_equal(results[r][0], refS)       # every rank holds the full set, in global cell order
+        if packed:                                       # the upper triangle travels, the lower one is its mirror
+            assert np.array_equal(results[r][0][:, iu[0], iu[1]], refS[:, iu[1], iu[0]])
+            assert np.array_equal(results[r][0], results[r][0].transpose(0, 2, 1))
+        else:
+            assert np.array_equal(results[r][0], refS)   # every rank holds the full set, in global cell order
         assert np.array_equal(results[r][1], refg)
