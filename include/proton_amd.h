@@ -263,6 +263,21 @@ int pa_cut_query(pa_context *ctx, size_t *ncut, int8_t *cell_location, int32_t *
 int pa_cut_local_ops_batch(pa_context *ctx, int face_deg, const pa_level_set *ls, int where, int rhs_fn, int bcs_fn,
                            double *d_oper, double *d_data, double *d_stab, double *d_lc, double *d_rhs,
                            int32_t *d_info);
+/* Tags and displaced coordinates left by pa_cut_preprocess (host arrays; any may be NULL):
+ * node_location npoints (of the UNDISPLACED mesh: detect_node_position is not re-run after
+ * move_nodes, cuthho_square.cpp:2036-2049), face_location nfaces, points npoints x 2. */
+int pa_cut_query_tags(pa_context *ctx, int8_t *node_location, int8_t *face_location, double *points);
+/* Quadrature lists of the cut cells as the cut integrate() overloads produce them
+ * (cuthho_geom.hpp:798-815, 851-895), for callers that sample their own functions:
+ * which = 0: integrate(msh, cl, 2*recdeg, where); 1: integrate_interface(msh, cl, 2*recdeg, where);
+ * 2: integrate_interface(msh, cl, recdeg, where) (the rule cut make_rhs uses, :647).  HOST outputs:
+ * h_offsets ncut+1, h_xyw count x 3; pass NULL to query *count. */
+int pa_cut_quadrature_points(pa_context *ctx, int face_deg, int where, int which, uint32_t *h_offsets, double *h_xyw,
+                             size_t *count);
+/* cut make_rhs (:623-666) with caller-sampled functions: d_rhs_vals at the points of list 0,
+ * d_bcs_vals at the points of list 2.  d_rhs ncut x cbs. */
+int pa_cut_rhs_sampled_batch(pa_context *ctx, int face_deg, const pa_level_set *ls, int where, const double *d_rhs_vals,
+                             const double *d_bcs_vals, double *d_rhs);
 /* Merge for the assembly loop of cuthho_square.cpp:883-900: rows of the cut cells in the
  * cell-major d_lc / d_rhs (all cells, from pa_local_ops_batch(PA_QUAD_FAN, PA_STAB_NAIVE) and
  * pa_cell_rhs_batch) are replaced by the cut operators; the right-hand side of uncut cells

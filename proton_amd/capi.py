@@ -29,6 +29,7 @@ EXPORTS = [
     "pa_obstacle_tables", "pa_obstacle_triplets_batch", "pa_obstacle_expand_solution",
     "pa_obstacle_take_local_data_batch",
     "pa_cut_preprocess", "pa_cut_query", "pa_cut_local_ops_batch", "pa_cut_merge",
+    "pa_cut_query_tags", "pa_cut_quadrature_points", "pa_cut_rhs_sampled_batch",
     "pa_cut_interface_ops_batch", "pa_cut_interface_uncut_batch", "pa_interface_assembler_query",
     "pa_interface_triplets_batch", "pa_interface_cell_offsets",
 ]
@@ -137,6 +138,9 @@ def lib():
     L.pa_cut_query.argtypes = [vp, C.POINTER(sz), vp, vp]
     L.pa_cut_local_ops_batch.argtypes = [vp, C.c_int, C.POINTER(LevelSet), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp]
     L.pa_cut_merge.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp]
+    L.pa_cut_query_tags.argtypes = [vp, vp, vp, vp]
+    L.pa_cut_quadrature_points.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(sz)]
+    L.pa_cut_rhs_sampled_batch.argtypes = [vp, C.c_int, C.POINTER(LevelSet), C.c_int, dp, dp, dp]
     L.pa_cut_interface_ops_batch.argtypes = [vp, C.c_int, C.POINTER(LevelSet), C.POINTER(InterfaceParams), C.c_int, dp, dp, dp, dp, dp]
     L.pa_cut_interface_uncut_batch.argtypes = [vp, C.c_int, C.POINTER(InterfaceParams), C.c_int, dp, dp, dp]
     L.pa_interface_assembler_query.argtypes = [vp, C.c_int, C.POINTER(InterfaceInfo)]
@@ -281,6 +285,21 @@ class Context:
     def obstacle_take_local_data(self, di, first, n, expanded, out):
         self._ck(self._L.pa_obstacle_take_local_data_batch(self.h, di, first, n, expanded, out),
                  "pa_obstacle_take_local_data_batch")
+
+    def cut_quadrature_points(self, face_deg, where, which):
+        """-> (offsets[ncut+1] uint32, xyw[count, 3]) host arrays"""
+        import numpy as np
+        n = C.c_size_t(0)
+        self._ck(self._L.pa_cut_quadrature_points(self.h, face_deg, where, which, None, None, C.byref(n)), "pa_cut_quadrature_points")
+        ncut = self.cut_query()[0]
+        off = np.zeros(ncut + 1, dtype=np.uint32)
+        xyw = np.zeros((n.value, 3))
+        self._ck(self._L.pa_cut_quadrature_points(self.h, face_deg, where, which, off.ctypes.data, xyw.ctypes.data, C.byref(n)),
+                 "pa_cut_quadrature_points")
+        return off, xyw
+
+    def cut_rhs_sampled(self, face_deg, ls, where, rhs_vals, bcs_vals, rhs):
+        self._ck(self._L.pa_cut_rhs_sampled_batch(self.h, face_deg, C.byref(ls), where, rhs_vals, bcs_vals, rhs), "pa_cut_rhs_sampled_batch")
 
     def cut_interface_ops(self, face_deg, ls, parms, rhs_fn, oper, data, lc, rhs, info):
         self._ck(self._L.pa_cut_interface_ops_batch(self.h, face_deg, C.byref(ls), C.byref(parms), rhs_fn, oper, data, lc, rhs, info),

@@ -924,14 +924,69 @@ static int ensure_cut_lists(pa_context *ctx, int face_deg, int where)
     return PA_OK;
 }
 
+static int cut_local_ops(pa_context *ctx, int face_deg, const pa_level_set *ls, int where, int rhs_fn, int bcs_fn,
+                         const double *d_rhs_vals, const double *d_bcs_vals,
+                         double *d_oper, double *d_data, double *d_stab, double *d_lc, double *d_rhs, int32_t *d_info);
+
 int pa_cut_local_ops_batch(pa_context *ctx, int face_deg, const pa_level_set *ls, int where, int rhs_fn, int bcs_fn,
                            double *d_oper, double *d_data, double *d_stab, double *d_lc, double *d_rhs, int32_t *d_info)
+{
+    if (rhs_fn <= PA_FN_SAMPLED || rhs_fn > PA_FN_ONE || bcs_fn <= PA_FN_SAMPLED || bcs_fn > PA_FN_ONE) return PA_ERR_INVALID_ARG;
+    return cut_local_ops(ctx, face_deg, ls, where, rhs_fn, bcs_fn, nullptr, nullptr, d_oper, d_data, d_stab, d_lc, d_rhs, d_info);
+}
+
+int pa_cut_rhs_sampled_batch(pa_context *ctx, int face_deg, const pa_level_set *ls, int where, const double *d_rhs_vals,
+                             const double *d_bcs_vals, double *d_rhs)
+{
+    if (!d_rhs_vals || !d_bcs_vals || !d_rhs) return PA_ERR_INVALID_ARG;
+    return cut_local_ops(ctx, face_deg, ls, where, PA_FN_SAMPLED, PA_FN_SAMPLED, d_rhs_vals, d_bcs_vals, nullptr, nullptr, nullptr,
+                         nullptr, d_rhs, nullptr);
+}
+
+int pa_cut_quadrature_points(pa_context *ctx, int face_deg, int where, int which, uint32_t *h_offsets, double *h_xyw,
+                             size_t *count)
+{
+    if (!ctx || (where != PA_LOC_NEGATIVE && where != PA_LOC_POSITIVE) || which < 0 || which > 2) return PA_ERR_INVALID_ARG;
+    if (!ctx->cut) return PA_ERR_NO_MESH;
+    if (face_deg < 0) return PA_ERR_INVALID_DEGREE;
+    if (face_deg > 2) return PA_ERR_QUADRATURE;
+    pa::CutLists L;
+    try {
+        pa::build_cut_lists(*ctx->cut, ctx->host_tab, face_deg, where, L);
+    } catch (const std::invalid_argument &ex) {
+        ctx->last_error = ex.what();
+        return PA_ERR_QUADRATURE;
+    } catch (const std::exception &ex) {
+        ctx->last_error = ex.what();
+        return PA_ERR_INVALID_ARG;
+    }
+    const std::vector<uint32_t> &off = which == 0 ? L.cell_off : which == 1 ? L.il_off : L.ir_off;
+    const std::vector<double> &xyw = which == 0 ? L.cell_xyw : which == 1 ? L.il_xyw : L.ir_xyw;
+    if (count) *count = xyw.size() / 3;
+    if (h_offsets) std::memcpy(h_offsets, off.data(), off.size() * sizeof(uint32_t));
+    if (h_xyw) std::memcpy(h_xyw, xyw.data(), xyw.size() * sizeof(double));
+    return PA_OK;
+}
+
+int pa_cut_query_tags(pa_context *ctx, int8_t *node_location, int8_t *face_location, double *points)
+{
+    if (!ctx) return PA_ERR_INVALID_ARG;
+    if (!ctx->cut) return PA_ERR_NO_MESH;
+    const pa::CutMeshHost &cm = *ctx->cut;
+    if (node_location) std::memcpy(node_location, cm.node_loc.data(), cm.npoints());
+    if (face_location) std::memcpy(face_location, cm.face_loc.data(), cm.nfaces());
+    if (points) std::memcpy(points, cm.pts.data(), cm.pts.size() * sizeof(double));
+    return PA_OK;
+}
+
+static int cut_local_ops(pa_context *ctx, int face_deg, const pa_level_set *ls, int where, int rhs_fn, int bcs_fn,
+                         const double *d_rhs_vals, const double *d_bcs_vals,
+                         double *d_oper, double *d_data, double *d_stab, double *d_lc, double *d_rhs, int32_t *d_info)
 {
     if (!ctx || !ls || (where != PA_LOC_NEGATIVE && where != PA_LOC_POSITIVE)) return PA_ERR_INVALID_ARG;
     if (!ctx->cut) return PA_ERR_NO_MESH;
     if (face_deg < 0) return PA_ERR_INVALID_DEGREE;
     if (face_deg > 2) return PA_ERR_QUADRATURE;            // 2*recdeg = 8 selects the empty rules[8]
-    if (rhs_fn <= PA_FN_SAMPLED || rhs_fn > PA_FN_ONE || bcs_fn <= PA_FN_SAMPLED || bcs_fn > PA_FN_ONE) return PA_ERR_INVALID_ARG;
     const size_t ncut = ctx->cut->cut_cells.size();
     if (ncut == 0) return PA_OK;
     int st = ensure_cut_lists(ctx, face_deg, where);
@@ -945,7 +1000,8 @@ int pa_cut_local_ops_batch(pa_context *ctx, int face_deg, const pa_level_set *ls
         a.cell_off = c.co; a.il_off = c.io; a.ir_off = c.ro;
         a.cell_xyw = c.cx; a.il_xyw = c.ix; a.ir_xyw = c.rx; a.fl_xyw = c.fl; a.fs_xyw = c.fs; a.fl_cnt = c.flc; a.fs_cnt = c.fsc;
         a.ls = pa::LevelSet{ls->kind, ls->radius, ls->alpha, ls->beta, ls->cut_y};
-        a.rhs_fn = rhs_fn; a.bcs_fn = bcs_fn; a.eta = 5.0;                       // cell_eta, cuthho_square.cpp:301-306
+        a.rhs_fn = rhs_fn; a.bcs_fn = bcs_fn; a.rhs_vals = d_rhs_vals; a.bcs_vals = d_bcs_vals;
+        a.eta = 5.0;                                                             // cell_eta, cuthho_square.cpp:301-306
         a.oper = d_oper; a.data = d_data; a.stab = d_stab; a.lc = d_lc; a.rhs = d_rhs; a.info = d_info;
         const int grid = (int)(ncut < (size_t)ctx->num_cus * 4 ? ncut : (size_t)ctx->num_cus * 4);
         switch (face_deg) {

@@ -27,7 +27,8 @@ struct CutArgs {
     const double *cell_xyw, *il_xyw, *ir_xyw, *fl_xyw, *fs_xyw;
     const int32_t *fl_cnt, *fs_cnt;
     LevelSet ls;
-    int rhs_fn, bcs_fn;
+    int rhs_fn, bcs_fn;             // FN_SAMPLED: values per point of the cell list / of the rhs interface list
+    const double *rhs_vals, *bcs_vals;
     double eta;                     // cell_eta, cuthho_square.cpp:301-306
     double *oper, *data, *stab, *lc, *rhs;
     int32_t *info;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                     S[oTPHI + l * ROWW + NPW + e] = vy;
                     vx *= bx; vy *= by;
                 }
-                S[oTPHI + l * ROWW + 2 * NPW] = a.rhs != nullptr ? builtin_fn(a.rhs_fn, x, y) : 0.0;
+                S[oTPHI + l * ROWW + 2 * NPW] = a.rhs == nullptr ? 0.0 : (a.rhs_fn == FN_SAMPLED ? a.rhs_vals[q] : builtin_fn(a.rhs_fn, x, y));
             }
             __syncthreads();
             const int nq = (int)((c1 - base) < (uint32_t)CH ? (c1 - base) : (uint32_t)CH);
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                     a.ls.normal(x, y, nx, ny);
                     S[oTPHI + 5 * l] = (x - barx) * ihalf;
                     S[oTPHI + 5 * l + 1] = (y - bary) * ihalf;
-                    S[oTPHI + 5 * l + 2] = a.ir_xyw[3 * q + 2] * builtin_fn(a.bcs_fn, x, y);
+                    S[oTPHI + 5 * l + 2] = a.ir_xyw[3 * q + 2] * (a.bcs_fn == FN_SAMPLED ? a.bcs_vals[q] : builtin_fn(a.bcs_fn, x, y));
                     S[oTPHI + 5 * l + 3] = nx;
                     S[oTPHI + 5 * l + 4] = ny;
                 }

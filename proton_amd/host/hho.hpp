@@ -285,6 +285,9 @@ template <typename T>
 struct quad_mesh {
     typedef point<T, 2> point_type;
     typedef T coordinate_type;
+    // integrate(msh, cl, degree) of this mesh type: tensor Gauss on the bilinear map
+    // (quadratures.hpp:311-375); cuthho_poly_mesh uses the triangle fan (:377-402)
+    static constexpr int pa_quadrature = PA_QUAD_TENSOR;
     struct cell_type {
         std::array<size_t, 4> ptids;
         bool operator<(const cell_type &o) const { return ptids < o.ptids; }
@@ -496,6 +499,13 @@ class batch_cache {
         }
     }
     void invalidate() { dev_mesh_ = mesh_on_device<Mesh>(); batches_.clear(); qpoints_.clear(); }
+    // the context already holds this mesh (pa_cut_preprocess built it): no upload
+    void adopt(const Mesh &m)
+    {
+        batches_.clear(); qpoints_.clear();
+        dev_mesh_.msh = &m; dev_mesh_.npoints = m.points.size(); dev_mesh_.ncells = m.cells.size();
+        dev_mesh_.probe = mesh_on_device<Mesh>::make_probe(m);
+    }
 
     std::shared_ptr<local_batch> get(const Mesh &m, const hho_degree_info &hdi, int quad, int stab)
     {
@@ -562,7 +572,7 @@ std::pair<proton_amd::dense_matrix<typename Mesh::coordinate_type>, proton_amd::
 make_hho_laplacian(const Mesh &msh, const typename Mesh::cell_type &cl, const hho_degree_info &di)
 {
     using T = typename Mesh::coordinate_type;
-    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, PA_QUAD_TENSOR, PA_STAB_FANCY);
+    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, Mesh::pa_quadrature, PA_STAB_FANCY);
     const size_t c = offset(msh, cl);
     return std::make_pair(proton_amd::copy_cell<T>(b->oper, c, b->sz.oper_rows, b->sz.msize),
                           proton_amd::copy_cell<T>(b->data, c, b->sz.msize, b->sz.msize));
@@ -574,7 +584,7 @@ proton_amd::dense_matrix<typename Mesh::coordinate_type>
 make_hho_naive_stabilization(const Mesh &msh, const typename Mesh::cell_type &cl, const hho_degree_info &di)
 {
     using T = typename Mesh::coordinate_type;
-    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, PA_QUAD_TENSOR, PA_STAB_NAIVE);
+    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, Mesh::pa_quadrature, PA_STAB_NAIVE);
     return proton_amd::copy_cell<T>(b->stab, offset(msh, cl), b->sz.msize, b->sz.msize);
 }
 
@@ -587,7 +597,7 @@ make_hho_fancy_stabilization(const Mesh &msh, const typename Mesh::cell_type &cl
                              const hho_degree_info &di)
 {
     using T = typename Mesh::coordinate_type;
-    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, PA_QUAD_TENSOR, PA_STAB_FANCY);
+    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, Mesh::pa_quadrature, PA_STAB_FANCY);
     return proton_amd::copy_cell<T>(b->stab, offset(msh, cl), b->sz.msize, b->sz.msize);
 }
 
@@ -601,14 +611,14 @@ make_rhs(const Mesh &msh, const typename Mesh::cell_type &cl, size_t degree, con
     auto &cache = proton_amd::batch_cache<Mesh>::instance();
     auto &dev = proton_amd::device::instance();
     int nq = 0;
-    const auto &xyw = cache.cell_qpoints(msh, (int)(2 * (degree + di)), PA_QUAD_TENSOR, nq);
+    const auto &xyw = cache.cell_qpoints(msh, (int)(2 * (degree + di)), Mesh::pa_quadrature, nq);
     const size_t c = offset(msh, cl);
     std::vector<double> fv(nq);
     for (int q = 0; q < nq; ++q) fv[q] = f(typename Mesh::point_type(xyw[(c * nq + q) * 3], xyw[(c * nq + q) * 3 + 1]));
     const size_t cbs = (degree + 2) * (degree + 1) / 2;
     proton_amd::device_buffer<double> d_f(nq), d_r(cbs);
     d_f.upload(fv.data(), nq);
-    dev.check(pa_cell_rhs_batch(dev.ctx(), (int)degree, (int)di, PA_QUAD_TENSOR, PA_FN_SAMPLED, d_f.get(), c, 1, d_r.get()),
+    dev.check(pa_cell_rhs_batch(dev.ctx(), (int)degree, (int)di, Mesh::pa_quadrature, PA_FN_SAMPLED, d_f.get(), c, 1, d_r.get()),
               "pa_cell_rhs_batch");
     proton_amd::dense_matrix<T> ret(cbs, 1);
     d_r.download(ret.data(), cbs);
@@ -632,7 +642,7 @@ project_function(const Mesh &msh, const typename Mesh::cell_type &cl, hho_degree
         auto &dev = proton_amd::device::instance();
         auto &bc = proton_amd::batch_cache<Mesh>::instance();
         int nq = 0;
-        const auto &xyw = bc.cell_qpoints(msh, (int)(2 * (cd + di)), PA_QUAD_TENSOR, nq);
+        const auto &xyw = bc.cell_qpoints(msh, (int)(2 * (cd + di)), Mesh::pa_quadrature, nq);
         std::vector<double> cv(n * nq);
         for (size_t k = 0; k < n * (size_t)nq; ++k) cv[k] = f(typename Mesh::point_type(xyw[3 * k], xyw[3 * k + 1]));
         const size_t nfq = fd + di + 1;
@@ -644,7 +654,7 @@ project_function(const Mesh &msh, const typename Mesh::cell_type &cl, hho_degree
         proton_amd::device_buffer<double> d_cv(cv.size()), d_fv(fv.size()), d_out(n * ms);
         d_cv.upload(cv.data(), cv.size());
         d_fv.upload(fv.data(), fv.size());
-        dev.check(pa_project_function_batch(dev.ctx(), hdi.c_abi(), PA_QUAD_TENSOR, (int)di, PA_FN_SAMPLED, d_cv.get(), d_fv.get(), 0, n,
+        dev.check(pa_project_function_batch(dev.ctx(), hdi.c_abi(), Mesh::pa_quadrature, (int)di, PA_FN_SAMPLED, d_cv.get(), d_fv.get(), 0, n,
                                             d_out.get(), nullptr), "pa_project_function_batch");
         cache.all.resize(n * ms);
         d_out.download(cache.all.data(), cache.all.size());
@@ -806,12 +816,12 @@ class assembler {
         auto &dev = proton_amd::device::instance();
         proton_amd::batch_cache<Mesh>::instance().ensure_mesh(msh);
         pa_sizes sz;
-        dev.check(pa_sizes_for(di.c_abi(), PA_QUAD_TENSOR, &sz), "pa_sizes_for");
+        dev.check(pa_sizes_for(di.c_abi(), Mesh::pa_quadrature, &sz), "pa_sizes_for");
         const size_t n = msh.cells.size(), ms = sz.msize, mm = ms * ms;
         proton_amd::device_buffer<double> d_lc(n * mm), d_rhs(n * sz.cbs), d_g(msh.faces.size() * sz.fbs), d_vals(n * mm), d_rv(n * ms);
         proton_amd::device_buffer<int32_t> d_rows(n * mm), d_cols(n * mm), d_rr(n * ms);
-        dev.check(pa_local_ops_batch(dev.ctx(), di.c_abi(), PA_QUAD_TENSOR, stab_kind, 0, n, nullptr, nullptr, nullptr, d_lc.get(), nullptr), "pa_local_ops_batch");
-        dev.check(pa_cell_rhs_batch(dev.ctx(), (int)di.cell_degree(), 0, PA_QUAD_TENSOR, rhs_fn, nullptr, 0, n, d_rhs.get()), "pa_cell_rhs_batch");
+        dev.check(pa_local_ops_batch(dev.ctx(), di.c_abi(), Mesh::pa_quadrature, stab_kind, 0, n, nullptr, nullptr, nullptr, d_lc.get(), nullptr), "pa_local_ops_batch");
+        dev.check(pa_cell_rhs_batch(dev.ctx(), (int)di.cell_degree(), 0, Mesh::pa_quadrature, rhs_fn, nullptr, 0, n, d_rhs.get()), "pa_cell_rhs_batch");
         dev.check(pa_dirichlet_data_batch(dev.ctx(), (int)di.face_degree(), dirichlet_fn, nullptr, d_g.get()), "pa_dirichlet_data_batch");
         dev.check(pa_triplets_batch(dev.ctx(), di.c_abi(), 0, n, d_lc.get(), d_rhs.get(), d_g.get(), d_rows.get(), d_cols.get(),
                                     d_vals.get(), d_rr.get(), d_rv.get()), "pa_triplets_batch");

@@ -46,6 +46,24 @@ def test_obstacle_driver_reproduces_committed_results(obstacle_driver, degree, N
 
 
 @pytest.fixture(scope="module")
+def cuthho_driver():
+    return _compile("cuthho_driver")
+
+
+@pytest.mark.parametrize("k,N,ref", [(0, 10, 0.188501), (1, 10, 1.1089e-2), (1, 20, 3.08508e-3), (2, 20, 9.30124e-5)])
+def test_cuthho_driver_reproduces_committed_results(cuthho_driver, k, N, ref):
+    """apps/cuthho `-f` through the drop-in header proton_amd/host/cuthho.hpp (the reference's step
+    functions, cut make_hho_laplacian / make_hho_cut_stabilization / make_rhs with host functors,
+    cut integrate) reproduces the F.D. table of apps/cuthho/cuthho.xlsx (r = 4)."""
+    r = subprocess.run([cuthho_driver, str(k), str(N), "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"cut_cells (\d+) .* energy_error ([0-9.e+-]+)", r.stdout)
+    assert m and int(m.group(1)) > 0, r.stdout
+    err = float(m.group(2))
+    assert abs(err - ref) / ref < 6e-6, r.stdout
+
+
+@pytest.fixture(scope="module")
 def driver():
     out_dir = os.path.join(ROOT, "tests", "cpp", "build")
     os.makedirs(out_dir, exist_ok=True)

@@ -72,6 +72,28 @@ def test_fictitious_domain_end_to_end_matches_xlsx(asm, oracle, N, k):
     assert abs(err - FD[(k, N)]) / FD[(k, N)] < 6e-6
 
 
+@pytest.mark.parametrize("N,k,where", [(10, 1, 0), (12, 2, 0), (10, 0, 1)])
+def test_cut_rhs_with_caller_sampled_functions(asm, N, k, where):
+    """pa_cut_quadrature_points + pa_cut_rhs_sampled_batch == the built-in source / boundary functions."""
+    import torch
+    import proton_amd as pa
+    asm.cut_preprocess(N, refsteps=4)
+    want = asm.cut_local_ops(k, where=where, want=("rhs",))["rhs"]
+    off0, xyw0 = asm.ctx.cut_quadrature_points(k, where, 0)
+    off2, xyw2 = asm.ctx.cut_quadrature_points(k, where, 2)
+    assert off0[-1] == len(xyw0) and off2[-1] == len(xyw2) and len(off0) == asm.ncut + 1
+    f = 2 * np.pi ** 2 * np.sin(np.pi * xyw0[:, 0]) * np.sin(np.pi * xyw0[:, 1])
+    b = np.sin(np.pi * xyw2[:, 0]) * np.sin(np.pi * xyw2[:, 1])
+    d_f = torch.from_numpy(f).to(asm.device)
+    d_b = torch.from_numpy(b).to(asm.device)
+    got = torch.empty_like(want)
+    asm.ctx.cut_rhs_sampled(k, asm.level_set, where, d_f.data_ptr(), d_b.data_ptr(), got.data_ptr())
+    asm.synchronize()
+    assert float((got - want).abs().max()) <= 1e-13 * max(1.0, float(want.abs().max()))
+    # the cut-cell rule integrates the area of the `where` side (weights sum to the sub-cell measure)
+    assert np.all(np.add.reduceat(xyw0[:, 2], off0[:-1].astype(np.int64)) > 0)
+
+
 def test_cut_error_codes(asm):
     import ctypes as C
     import proton_amd as pa
