@@ -43,6 +43,10 @@ WORKLOADS = {
     "cuthho512_k2": dict(N=512, cd=3, fd=2, quad="fan", stab="naive", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0, cut=True,
                          note="configs[2]: cuthho_square -M 512 -N 512 -k 2 -f, circle r=0.35, -r 4, node displacement: "
                               "uncut cells (fan quadrature, naive stabilization) + cut cells (Nitsche operators), merged"),
+    "quad1024_k2_general": dict(N=1024, cd=3, fd=2, quad="tensor", stab="fancy", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0, perturb=0.1,
+                                note="the headline on GENERAL quadrilaterals: interior nodes displaced by U(-0.1 h, 0.1 h) (the commented-out "
+                                     "perturbation of convergence_test.cpp:176-187, numpy default_rng(12345)): no two cells are congruent, "
+                                     "so nothing can be reused between cells"),
     "quad1024_k1": dict(N=1024, cd=2, fd=1, quad="tensor", stab="fancy", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0,
                         note="1024x1024 k=1"),
     "quad1024_k3": dict(N=1024, cd=4, fd=3, quad="tensor", stab="fancy", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0,
@@ -75,13 +79,49 @@ def cpu_baseline_cut(w, target_seconds=15.0):
                       % (N, N, msh.nc, ncut, dt)}
 
 
+def perturbation(N, lo, hi, amount):
+    """displacements of the interior nodes, U(-amount h, amount h), numpy default_rng(12345) -- the same
+    array for the GPU mesh and for the CPU baseline's mesh"""
+    import numpy as np
+    rng = np.random.default_rng(12345)
+    h = (hi[0] - lo[0]) / N
+    d = rng.uniform(-amount * h, amount * h, size=((N + 1) * (N + 1), 2))
+    ij = np.arange((N + 1) * (N + 1))
+    i, j = ij % (N + 1), ij // (N + 1)
+    d[~((i > 0) & (i < N) & (j > 0) & (j < N))] = 0.0
+    return d
+
+
+def general_quad_mesh(torch, N, lo, hi, amount, device):
+    """The generator mesh (basic_mesh.hpp:230-298: points min + i h, cells {p, p+1, p+Nx+2, p+Nx+1})
+    with displaced interior nodes, built directly as device arrays."""
+    i = torch.arange(N + 1, dtype=torch.float64, device=device)
+    hx, hy = (hi[0] - lo[0]) / N, (hi[1] - lo[1]) / N
+    pts = torch.stack([(lo[0] + i * hx).repeat(N + 1), (lo[1] + i * hy).repeat_interleave(N + 1)], dim=1).contiguous()
+    pts += torch.from_numpy(perturbation(N, lo, hi, amount)).to(device)
+    ci = torch.arange(N, device=device, dtype=torch.int64)
+    p0 = (ci.repeat_interleave(N) * (N + 1) + ci.repeat(N))                    # cell (i, j) -> j (Nx+1) + i, cell id = j Nx + i
+    ptids = torch.stack([p0, p0 + 1, p0 + N + 2, p0 + N + 1], dim=1).to(torch.int32).contiguous()    # ids < 2^31: same bits as u32
+    return pts, ptids
+
+
+def workload_mesh(w):
+    """host arrays of the workload's mesh for the CPU baseline (oracle side)"""
+    import oracle_lib
+    N = w["N"]
+    mp, points, ptids = oracle_lib.make_mesh(N, N, w["lo"], w["hi"])
+    if w.get("perturb"):
+        points += perturbation(N, w["lo"], w["hi"], w["perturb"])
+    return points, ptids
+
+
 def cpu_baseline(w, sample_rows, target_seconds=15.0):
     """The oracle (CPU restatement, single thread like the reference) on a bounded sample of the
     same workload: the first `sample_rows` cell rows of the same mesh (0 = as many rows as take
     about `target_seconds` at the rate measured on a small probe)."""
     import oracle_lib
     N = w["N"]
-    mp, points, ptids = oracle_lib.make_mesh(N, N, w["lo"], w["hi"])
+    points, ptids = workload_mesh(w)
     di = oracle_lib.degrees(w["cd"], w["fd"])
     quad = oracle_lib.QUAD_TENSOR if w["quad"] == "tensor" else oracle_lib.QUAD_FAN
     stab = oracle_lib.STAB_FANCY if w["stab"] == "fancy" else oracle_lib.STAB_NAIVE
@@ -158,6 +198,11 @@ def main():
         if world > 1:
             raise SystemExit("the cut workload is single-GPU in this round")
         asm.cut_preprocess(N, refsteps=4)                    # host preprocessing: outside the timed region
+    elif w.get("perturb"):
+        if world > 1:
+            raise SystemExit("the general-quadrilateral workload is single-GPU in this round")
+        mesh_keep = general_quad_mesh(torch, N, w["lo"], w["hi"], w["perturb"], asm.device)     # caller-owned device arrays
+        asm.ctx.mesh_attach_device(mesh_keep[0].data_ptr(), (N + 1) * (N + 1), mesh_keep[1].data_ptr(), N * N)
     else:
         asm.generate_mesh(N, N, w["lo"], w["hi"], rows=(r0, r1))
     n_local = asm.ncells

@@ -244,6 +244,46 @@ def test_full_size_properties(asm, oracle, N, cd, fd):
         assert nerr(got, r["lc"][0]) < TOL
 
 
+def test_config5_slabs_2048_k3(asm, oracle):
+    """configs[4] of BASELINE.json: 2048 x 2048, hho_degree_info(4,3), cell rows block-partitioned over
+    8 ranks -- here the 8 slabs run one after the other on the one GPU (4 GB of lc each).  Every
+    slab: finite, SPD pivots, symmetric, constants in the kernel, equal to the oracle's cell 0 up to
+    the rounding of the coordinates; the first cell of each slab against the oracle proper."""
+    import torch
+    import proton_amd as pa
+    from proton_amd.partition import row_partition
+    N, cd, fd = 2048, 4, 3
+    di = oracle.degrees(cd, fd)
+    mp, points, ptids = oracle.make_mesh(N, N)
+    st, ref = oracle.local_ops_batch(points, ptids, di, pa.QUAD_TENSOR, pa.STAB_FANCY, first=0, n=1, want=("lc",))
+    ref0 = None
+    out = None
+    for rank in range(8):
+        r0, r1 = row_partition(N, 8, rank)
+        asm.generate_mesh(N, N, rows=(r0, r1))
+        assert asm.ncells == (r1 - r0) * N
+        out = asm.local_ops(cd, fd, pa.QUAD_TENSOR, pa.STAB_FANCY, want=("lc", "info"), out=out)
+        asm.synchronize()
+        lc = out["lc"]
+        if ref0 is None:
+            ref0 = torch.from_numpy(ref["lc"][0].T.copy()).to(lc.device)
+            one = torch.zeros(di.msize, dtype=torch.float64, device=lc.device)
+            one[0] = 1.0
+            one[di.cbs::di.fbs] = 1.0
+        assert int(out["info"].abs().max().cpu()) == 0
+        worst_sym = worst_ker = worst_ref = 0.0
+        for a in range(0, lc.shape[0], 65536):                 # chunks: no second 4 GB temporary
+            blk = lc[a:a + 65536]
+            scale = float(ref0.abs().max())
+            worst_sym = max(worst_sym, float((blk - blk.transpose(1, 2)).abs().max()) / scale)
+            worst_ker = max(worst_ker, float((blk @ one).abs().max()) / scale)
+            worst_ref = max(worst_ref, float((blk - ref0).abs().max()) / scale)
+        assert worst_sym < TOL and worst_ker < 1e-10 and worst_ref < 1e-9, (rank, worst_sym, worst_ker, worst_ref)
+        c = r0 * N
+        st, r = oracle.local_ops_batch(points, ptids, di, pa.QUAD_TENSOR, pa.STAB_FANCY, first=c, n=1, want=("lc",))
+        assert nerr(lc[0].cpu().numpy().T, r["lc"][0]) < TOL
+
+
 @pytest.mark.parametrize("N,degree", [(16, 0), (16, 1), (32, 1)])
 def test_obstacle_end_to_end_on_gpu_operators(asm, N, degree):
     """configs[3] plumbing: the obstacle driver (apps/obstacle/obstacle.cpp:47-227) fed with the GPU's
