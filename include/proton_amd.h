@@ -239,6 +239,14 @@ int pa_obstacle_expand_solution(pa_context *ctx, pa_degree_info di, const double
 int pa_obstacle_take_local_data_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n,
                                       const double *d_expanded, double *d_out);
 
+/* SparseMatrix::setFromTriplets (hho.hpp:451-455, :746-750; cuthho_square.cpp:1437-1441) on the
+ * device: nslots triplet slots (a negative row or column = a slot the assembler did not push) ->
+ * CSR with duplicates summed in push order.  d_rowptr nrows+1 (int64), d_colind / d_values with room
+ * for nslots entries (the worst case); *nnz (host) receives the number of stored entries.
+ * Column indices are ascending within a row.  nslots < 2^31. */
+int pa_csr_from_triplets(pa_context *ctx, size_t nslots, const int32_t *d_rows, const int32_t *d_cols, const double *d_vals,
+                         size_t nrows, int64_t *d_rowptr, int32_t *d_colind, double *d_values, size_t *nnz);
+
 /* ---- cutHHO (fictitious domain, `cuthho_square -f`) -----------------------------------------
  * circle_level_set / line_level_set, apps/cuthho/cuthho_square.cpp:56-124 */
 typedef struct { int32_t kind; double radius, alpha, beta, cut_y; } pa_level_set;   /* kind 0 circle, 1 line */

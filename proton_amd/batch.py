@@ -125,6 +125,17 @@ class BatchAssembler:
                           vals.data_ptr(), rhs_rows.data_ptr(), rhs_vals.data_ptr())
         return rows, cols, vals, rhs_rows, rhs_vals
 
+    def csr_from_triplets(self, rows, cols, vals, nrows):
+        """setFromTriplets on the device -> (rowptr int64 [nrows+1], colind int32 [nnz], values [nnz])."""
+        rows, cols, vals = rows.reshape(-1), cols.reshape(-1), vals.reshape(-1)
+        n = rows.numel()
+        rowptr = torch.empty(nrows + 1, dtype=torch.int64, device=self.device)
+        colind = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        values = torch.empty(max(n, 1), dtype=torch.float64, device=self.device)
+        nnz = self.ctx.csr_from_triplets(n, rows.data_ptr(), cols.data_ptr(), vals.data_ptr(), nrows, rowptr.data_ptr(),
+                                         colind.data_ptr(), values.data_ptr())
+        return rowptr, colind[:nnz], values[:nnz]
+
     def take_local_data(self, cd, fd, solution, g=None, first=0, n=None):
         """assembler::take_local_data (hho.hpp:408-449) for cells [first, first+n) -> n x msize."""
         di, _ = capi.degree_info(cd, fd)

@@ -25,7 +25,7 @@ EXPORTS = [
     "pa_local_ops_batch", "pa_cell_rhs_batch", "pa_cell_quadrature_points",
     "pa_static_condensation_batch", "pa_static_condensation_packed_batch", "pa_local_ops_launch_info",
     "pa_mesh_set_faces", "pa_assembler_query", "pa_dirichlet_data_batch", "pa_face_quadrature_points",
-    "pa_triplets_batch", "pa_take_local_data_batch", "pa_project_function_batch", "pa_energy_form_batch",
+    "pa_triplets_batch", "pa_csr_from_triplets", "pa_take_local_data_batch", "pa_project_function_batch", "pa_energy_form_batch",
     "pa_obstacle_tables", "pa_obstacle_triplets_batch", "pa_obstacle_expand_solution",
     "pa_obstacle_take_local_data_batch",
     "pa_cut_preprocess", "pa_cut_query", "pa_cut_local_ops_batch", "pa_cut_merge",
@@ -127,6 +127,7 @@ def lib():
     L.pa_dirichlet_data_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.pa_face_quadrature_points.argtypes = [vp, C.c_int, dp]
     L.pa_triplets_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp, dp, dp, dp, dp, dp]
+    L.pa_csr_from_triplets.argtypes = [vp, sz, dp, dp, dp, sz, dp, dp, dp, C.POINTER(sz)]
     L.pa_take_local_data_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp]
     L.pa_project_function_batch.argtypes = [vp, DegreeInfo, C.c_int, C.c_int, C.c_int, dp, dp, sz, sz, dp, dp]
     L.pa_energy_form_batch.argtypes = [vp, DegreeInfo, sz, dp, dp, dp, dp]
@@ -258,6 +259,12 @@ class Context:
     def triplets(self, di, first, n, lc, rhs, g, rows, cols, vals, rhs_rows, rhs_vals):
         self._ck(self._L.pa_triplets_batch(self.h, di, first, n, lc, rhs, g, rows, cols, vals, rhs_rows, rhs_vals),
                  "pa_triplets_batch")
+
+    def csr_from_triplets(self, nslots, rows, cols, vals, nrows, rowptr, colind, values):
+        nnz = C.c_size_t(0)
+        self._ck(self._L.pa_csr_from_triplets(self.h, nslots, rows, cols, vals, nrows, rowptr, colind, values, C.byref(nnz)),
+                 "pa_csr_from_triplets")
+        return nnz.value
 
     def take_local_data(self, di, first, n, solution, g, out):
         self._ck(self._L.pa_take_local_data_batch(self.h, di, first, n, solution, g, out), "pa_take_local_data_batch")

@@ -54,6 +54,11 @@ int min_lanes(int cd, int fd, int quad)
 
 }  // namespace
 
+namespace pa {
+hipError_t csr_from_triplets(hipStream_t stream, size_t n, const int32_t *d_rows, const int32_t *d_cols, const double *d_vals,
+                             size_t nrows, int64_t *d_rowptr, int32_t *d_colind, double *d_values, size_t *nnz_out);   // csr.hip
+}
+
 struct pa_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -558,6 +563,15 @@ int pa_obstacle_expand_solution(pa_context *ctx, pa_degree_info di, const double
     const uint64_t total = a.ncells * a.cbs + a.nfaces * a.fbs;
     hipLaunchKernelGGL(pa::obstacle_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, a);
     PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
+int pa_csr_from_triplets(pa_context *ctx, size_t nslots, const int32_t *d_rows, const int32_t *d_cols, const double *d_vals,
+                         size_t nrows, int64_t *d_rowptr, int32_t *d_colind, double *d_values, size_t *nnz)
+{
+    if (!ctx || !d_rowptr || (nslots && (!d_rows || !d_cols || !d_vals || !d_colind || !d_values))) return PA_ERR_INVALID_ARG;
+    if (nslots >= ((size_t)1 << 31) || nrows >= ((size_t)1 << 31)) return PA_ERR_INVALID_ARG;
+    PA_HIP(ctx, pa::csr_from_triplets(ctx->stream, nslots, d_rows, d_cols, d_vals, nrows, d_rowptr, d_colind, d_values, nnz));
     return PA_OK;
 }
 

@@ -802,13 +802,19 @@ class assembler {
         return ret;
     }
 
-    // hho.hpp:451-455: LHS.setFromTriplets (duplicates summed)
+    // hho.hpp:451-455: LHS.setFromTriplets (duplicates summed).  After assemble_all() the CSR was
+    // already built on the device.
     void finalize(void)
     {
+        if (device_csr_) { device_csr_ = false; return; }
         LHS.set_from_triplets(RHS.size(), triplets);
         triplets.clear();
     }
 
+  private:
+    bool device_csr_ = false;
+
+  public:
     // Batched equivalent of the whole loop of convergence_test.cpp:202-215 with built-in source
     // terms: local operators, right-hand sides, Dirichlet data and triplets on the device.
     void assemble_all(const Mesh &msh, int stab_kind, int rhs_fn, int dirichlet_fn)
@@ -825,12 +831,21 @@ class assembler {
         dev.check(pa_dirichlet_data_batch(dev.ctx(), (int)di.face_degree(), dirichlet_fn, nullptr, d_g.get()), "pa_dirichlet_data_batch");
         dev.check(pa_triplets_batch(dev.ctx(), di.c_abi(), 0, n, d_lc.get(), d_rhs.get(), d_g.get(), d_rows.get(), d_cols.get(),
                                     d_vals.get(), d_rr.get(), d_rv.get()), "pa_triplets_batch");
-        std::vector<int32_t> rows(n * mm), cols(n * mm), rr(n * ms);
-        std::vector<double> vals(n * mm), rv(n * ms);
-        d_rows.download(rows.data(), rows.size()); d_cols.download(cols.data(), cols.size());
-        d_vals.download(vals.data(), vals.size()); d_rr.download(rr.data(), rr.size()); d_rv.download(rv.data(), rv.size());
-        for (size_t k = 0; k < rows.size(); ++k)
-            if (rows[k] >= 0) triplets.emplace_back(rows[k], cols[k], vals[k]);
+        // setFromTriplets on the device (pa_csr_from_triplets): only the CSR arrays come back
+        proton_amd::device_buffer<int64_t> d_rowptr(RHS.size() + 1);
+        proton_amd::device_buffer<int32_t> d_colind(n * mm);
+        proton_amd::device_buffer<double> d_values(n * mm);
+        size_t nnz = 0;
+        dev.check(pa_csr_from_triplets(dev.ctx(), n * mm, d_rows.get(), d_cols.get(), d_vals.get(), RHS.size(), d_rowptr.get(),
+                                       d_colind.get(), d_values.get(), &nnz), "pa_csr_from_triplets");
+        LHS.nrows = LHS.ncols = RHS.size();
+        LHS.rowptr.resize(RHS.size() + 1); LHS.colind.resize(nnz); LHS.values.resize(nnz);
+        d_rowptr.download(LHS.rowptr.data(), LHS.rowptr.size());
+        if (nnz) { d_colind.download(LHS.colind.data(), nnz); d_values.download(LHS.values.data(), nnz); }
+        device_csr_ = true;
+        std::vector<int32_t> rr(n * ms);
+        std::vector<double> rv(n * ms);
+        d_rr.download(rr.data(), rr.size()); d_rv.download(rv.data(), rv.size());
         for (size_t k = 0; k < rr.size(); ++k)
             if (rr[k] >= 0) RHS[rr[k]] += rv[k];
     }
@@ -945,10 +960,15 @@ class obstacle_assembler {
 
     void finalize(void)
     {
+        if (device_csr_) { device_csr_ = false; return; }       // assemble_all() built the CSR on the device
         LHS.set_from_triplets(RHS.size(), triplets);
         triplets.clear();
     }
 
+  private:
+    bool device_csr_ = false;
+
+  public:
     // The whole cell loop of obstacle.cpp:148-156 on the device (pa_obstacle_tables +
     // pa_obstacle_triplets_batch): d_lc / d_rhs / d_g are device arrays for all cells / faces.
     void assemble_all(const Mesh &msh, const double *d_lc, const double *d_rhs, const double *d_g, const std::vector<T> &gamma)
@@ -968,12 +988,20 @@ class obstacle_assembler {
         dev.check(pa_obstacle_triplets_batch(dev.ctx(), di.c_abi(), 0, n, d_lc, d_rhs, d_g, d_gamma.get(), d_in.get(), d_a.get(),
                                              d_b.get(), ni, d_rows.get(), d_cols.get(), d_vals.get(), d_rr.get(), d_rv.get()),
                   "pa_obstacle_triplets_batch");
-        std::vector<int32_t> rows(n * slots), cols(n * slots), rr(n * ms);
-        std::vector<double> vals(n * slots), rv(n * ms);
-        d_rows.download(rows.data(), rows.size()); d_cols.download(cols.data(), cols.size());
-        d_vals.download(vals.data(), vals.size()); d_rr.download(rr.data(), rr.size()); d_rv.download(rv.data(), rv.size());
-        for (size_t k = 0; k < rows.size(); ++k)
-            if (rows[k] >= 0) triplets.emplace_back(rows[k], cols[k], vals[k]);
+        proton_amd::device_buffer<int64_t> d_rowptr(RHS.size() + 1);          // setFromTriplets on the device
+        proton_amd::device_buffer<int32_t> d_colind(n * slots);
+        proton_amd::device_buffer<double> d_values(n * slots);
+        size_t nnz = 0;
+        dev.check(pa_csr_from_triplets(dev.ctx(), n * slots, d_rows.get(), d_cols.get(), d_vals.get(), RHS.size(), d_rowptr.get(),
+                                       d_colind.get(), d_values.get(), &nnz), "pa_csr_from_triplets");
+        LHS.nrows = LHS.ncols = RHS.size();
+        LHS.rowptr.resize(RHS.size() + 1); LHS.colind.resize(nnz); LHS.values.resize(nnz);
+        d_rowptr.download(LHS.rowptr.data(), LHS.rowptr.size());
+        if (nnz) { d_colind.download(LHS.colind.data(), nnz); d_values.download(LHS.values.data(), nnz); }
+        device_csr_ = true;
+        std::vector<int32_t> rr(n * ms);
+        std::vector<double> rv(n * ms);
+        d_rr.download(rr.data(), rr.size()); d_rv.download(rv.data(), rv.size());
         for (size_t k = 0; k < rr.size(); ++k)
             if (rr[k] >= 0) RHS[rr[k]] += rv[k];
     }

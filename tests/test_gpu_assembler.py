@@ -119,3 +119,53 @@ def test_config1_plumbing_poisson_solve(asm, oracle, cd, fd):
         assert np.abs(sol - sol_o).max() < 1e-9
         errs.append(pd.l2_error(ref, di, sol))
     assert math.log2(errs[0] / errs[1]) > fd + 2 - 0.3
+
+
+@pytest.mark.parametrize("N,cd,fd", [(6, 2, 1), (9, 3, 2), (5, 0, 1)])
+def test_device_csr_equals_set_from_triplets(asm, N, cd, fd):
+    """pa_csr_from_triplets == scipy's COO -> CSR with summed duplicates (SparseMatrix::setFromTriplets,
+    hho.hpp:451-455): structure bit-exact, values exact (a face-face entry is the sum of at most two
+    contributions, and two-term sums do not depend on the order)."""
+    import scipy.sparse as sp
+    lc, rhs, g, r, c, v, rr, rv = gpu_assembly(asm, N, cd, fd)
+    info = asm.assembler_info(cd, fd)
+    rowptr, colind, values = asm.csr_from_triplets(r, c, v, info.system_size)
+    asm.synchronize()
+    R, Cc, V = r.cpu().numpy().ravel(), c.cpu().numpy().ravel(), v.cpu().numpy().ravel()
+    keep = R >= 0
+    ref = sp.coo_matrix((V[keep], (R[keep], Cc[keep])), shape=(info.system_size, info.system_size)).tocsr()
+    ref.sum_duplicates(); ref.sort_indices()
+    assert np.array_equal(rowptr.cpu().numpy(), ref.indptr.astype(np.int64))
+    assert np.array_equal(colind.cpu().numpy(), ref.indices.astype(np.int32))
+    assert np.array_equal(values.cpu().numpy(), ref.data)
+    assert int(rowptr[-1]) == ref.nnz
+
+
+def test_device_csr_edge_cases(asm):
+    """empty input, all slots dropped, long runs of duplicates summed in push order, sizes around the scan tile"""
+    import torch
+    dev = asm.device
+    rp, ci, va = asm.csr_from_triplets(torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev),
+                                       torch.empty(0, dtype=torch.float64, device=dev), 4)
+    assert rp.tolist() == [0, 0, 0, 0, 0] and ci.numel() == 0
+    m1 = torch.full((10,), -1, dtype=torch.int32, device=dev)
+    rp, ci, va = asm.csr_from_triplets(m1, m1, torch.ones(10, dtype=torch.float64, device=dev), 3)
+    assert rp.tolist() == [0, 0, 0, 0] and ci.numel() == 0
+    rng = np.random.default_rng(0)
+    for n in (1, 2047, 2048, 2049, 100_000):
+        rows = rng.integers(0, 50, n).astype(np.int32)
+        cols = rng.integers(0, 7, n).astype(np.int32)
+        vals = rng.standard_normal(n)
+        drop = rng.random(n) < 0.2
+        rows[drop] = -1
+        rp, ci, va = asm.csr_from_triplets(torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev), torch.from_numpy(vals).to(dev), 50)
+        want = {}
+        for i in range(n):                                  # left-to-right sums, the order of the pushes
+            if rows[i] >= 0:
+                want[(int(rows[i]), int(cols[i]))] = want.get((int(rows[i]), int(cols[i])), 0.0) + vals[i]
+        keys = sorted(want)
+        rp, ci, va = rp.cpu().numpy(), ci.cpu().numpy(), va.cpu().numpy()
+        assert len(keys) == len(ci) == rp[-1]
+        got_rows = np.repeat(np.arange(50), np.diff(rp))
+        assert [(int(a), int(b)) for a, b in zip(got_rows, ci)] == keys
+        assert np.array_equal(va, np.array([want[k] for k in keys]))
