@@ -75,6 +75,7 @@ __host__ __device__ constexpr int dunavant_points(int deg)
 }
 __host__ __device__ constexpr int gauss_nodes(int deg) { return ((deg | 1) + 1) / 2; }
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ constexpr int imin(int a, int b) { return a < b ? a : b; }
 __host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 
 template <int CD_, int FD_, int QUAD_, int STAB_, int G_>
@@ -117,6 +118,12 @@ struct Cfg {
     static constexpr int oDN = (oPHF + NFP * RBS + 1) & ~1;   // NFP x NRP  (w_q/2) (grad phi . edge normal)
     static constexpr int oMOM = oDN + NFP * NRP;              // NMOM moments
     static constexpr int endQ = oMOM + NMOM;
+    // gr_rhs cell columns are assembled by SPC lanes each (RPP rows per lane) and meet in GRC, which
+    // lies on the w*bx^e / by^e tables (dead after the moments)
+    // (measured: -1.7 % at k = 2, nothing at k = 3, +1 % with 16 lanes per cell -> only for G = 32)
+    static constexpr int SPC = G >= 32 ? imin(G / CBS, NR) : 1, RPP = cdiv(NR, SPC < 1 ? 1 : SPC);
+    static constexpr int oGRC = 0;                            // CBS x NRP
+    static_assert(SPC <= 1 || CBS * NRP <= 2 * NQ * NPW, "GRC must fit the dead quadrature tables");
     static constexpr int oZ = 0;                              // ZS x MS    (written from S5 on)
     static constexpr int oOUT = 0;                            // MS x MS    (written in S8, after the last read of Z)
     static constexpr int sizeQ = imax(imax(endQ, ZS * MS), MS * MS);
@@ -601,9 +608,30 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
         double col[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) col[i] = 1.0;
+        // Cell columns: stiff[1:, c] minus sum_pf (w dphi.n)[pf][:] phi_c(x_pf).  The NR rows of a column
+        // are split over SPC lanes (there are only CBS cell columns for G lanes); the pieces meet in
+        // the GRC scratch (on the dead quadrature tables) and the column owner reloads them after
+        // the barrier below.
+        constexpr int SPC = C::SPC, RPP = C::RPP;
         if (a.ablate & 4u) {
+        } else if (SPC > 1) {
+            if (l < SPC * CBS) {
+                const int part = l / CBS, cc = l % CBS, r0 = part * RPP;
+                double acc[RPP];
+#pragma unroll
+                for (int r = 0; r < RPP; ++r) acc[r] = S[C::oST + 1 + (r0 + r < NR ? r0 + r : NR - 1) + cc * LD];
+#pragma unroll
+                for (int pf = 0; pf < NFP; ++pf) {
+                    const double ph = S[C::oPHF + pf * RBS + cc];
+                    const double *dn = S + C::oDN + pf * NRP + r0;
+#pragma unroll
+                    for (int r = 0; r < RPP; ++r) acc[r] = __builtin_fma(-dn[r], ph, acc[r]);      // rows >= NR: unused
+                }
+#pragma unroll
+                for (int r = 0; r < RPP; ++r)
+                    if (r0 + r < NR) S[C::oGRC + cc * NRP + r0 + r] = acc[r];
+            }
         } else if (l < CBS) {
-            // stiff[1:, c] (contiguous, aligned) minus sum_pf (w dphi.n)[pf][:] phi_c(x_pf)
             const double *stc = S + C::oST + 1 + c * LD;
 #pragma unroll
             for (int i = 0; i + 1 < NR; i += 2) {
@@ -623,6 +651,9 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                 }
                 if (NR & 1) col[NR - 1] = __builtin_fma(-dn[NR - 1], ph, col[NR - 1]);
             }
+        }
+        if (a.ablate & 4u) {
+        } else if (l < CBS) {
         } else {
 #pragma unroll
             for (int i = 0; i < NR; ++i) col[i] = 0.0;
@@ -638,6 +669,26 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                 if (NR & 1) col[NR - 1] = __builtin_fma(dn[NR - 1], fbq[q], col[NR - 1]);
             }
         }
+        __syncthreads();
+        if (SPC > 1 && l < CBS && !(a.ablate & 4u)) {
+            const double *gc = S + C::oGRC + c * NRP;
+#pragma unroll
+            for (int i = 0; i + 1 < NR; i += 2) {
+                const double2 v = lds_pair(gc + i);
+                col[i] = v.x; col[i + 1] = v.y;
+            }
+            if (NR & 1) col[NR - 1] = gc[NR - 1];
+        }
+
+        // ================= S4/S5: L L^T = gr_lhs (in place in ST[1:,1:]) ; Y = L^-1 gr_rhs  hho.hpp:63,92
+        PA_MARK("S4");
+        double *LG = S + C::oST + 1 + LD;        // stiff[1:,1:], symmetric: row-major == column-major
+        int bad = 0;
+        if (!(a.ablate & 8u)) bad = lds_cholesky<NR, LD, G>(LG, l);
+        if (!(a.ablate & 16u)) lds_forward<NR, LD>(LG, col);
+        // The trace columns are formed only now (not next to the gr_rhs columns in S3b): they stay
+        // out of the register budget of the factorization.  They read the face tables of region Q,
+        // which Z overwrites: Y goes to LDS after the barrier below.
         // trace columns / (|F|/2):  tr[fk] = sum_q w_q t_q^k phi_c(x_fq)   hho.hpp:209-216 / 133-140.
         // Point q of face f IS the reference's q-th face point (S1 mirrors t for faces whose lower-id
         // endpoint comes second), so its face-basis value is t_q^k for either orientation.
@@ -663,13 +714,6 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
             }
         }
         __syncthreads();
-
-        // ================= S4/S5: L L^T = gr_lhs (in place in ST[1:,1:]) ; Y = L^-1 gr_rhs  hho.hpp:63,92
-        PA_MARK("S4");
-        double *LG = S + C::oST + 1 + LD;        // stiff[1:,1:], symmetric: row-major == column-major
-        int bad = 0;
-        if (!(a.ablate & 8u)) bad = lds_cholesky<NR, LD, G>(LG, l);
-        if (!(a.ablate & 16u)) lds_forward<NR, LD>(LG, col);
         if (l < MS) {
 #pragma unroll
             for (int k = 0; k < NR; ++k) S[C::oZ + k + c * ZS] = col[k];
