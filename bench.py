@@ -54,6 +54,10 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6      # 256 CU x 4 SIMD x 16 FMA/clk x 2 x 2.4 GHz; v_mfma_f64_16x16x4_f64 measured at 64 clk = the same rate
+# FP64 work of the REFERENCE's algorithm per cell (hand operation-count model, +-30 %)
+REFERENCE_FLOPS_PER_CELL = {(2, 1, "tensor", "fancy"): 16.7e3, (2, 1, "fan", "naive"): 14.7e3, (3, 2, "fan", "naive"): 60.5e3,
+                            (3, 2, "tensor", "fancy"): 67.1e3, (0, 1, "tensor", "fancy"): 9.1e3, (4, 3, "tensor", "fancy"): 197.5e3}
 
 
 def bytes_per_cell(msize, cbs):
@@ -306,6 +310,15 @@ def main():
                          "algorithmic_bytes_per_cell": bpc, "cells_per_launch": n_local,
                          "lanes_per_cell": li.lanes_per_cell, "grid_blocks": li.grid_blocks,
                          "lds_bytes_per_block": li.lds_bytes_per_block},
+            # the survey's second roof: the path is FP64-bound, not HBM-bound, for k >= 2 (arithmetic intensity of the
+            # reference's algorithm 17-25 flop/B against a machine balance of 9.8).  Informational: the kernel executes
+            # fewer flops than the reference's algorithm (cell integrals through moments), so this is work done per
+            # reference flop, not an instruction-level utilisation.
+            "roofline_fp64": (lambda fl: None if fl is None else {
+                "bound": "fp64", "achieved": n_local * fl / (kern_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": n_local * fl / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "reference_flops_per_cell": fl, "source": "SURVEY.md 8(d) operation-count model of the reference's algorithm, +-30 %"})(
+                    REFERENCE_FLOPS_PER_CELL.get((w["cd"], w["fd"], w["quad"], w["stab"]))),
             "kernel_only_cells_per_s": total_cells / (kern_ms * 1e-3) if world == 1 else n_local * world / (kern_ms * 1e-3),
         }
         if not args.no_cpu_baseline and world == 1:
