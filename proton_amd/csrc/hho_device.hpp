@@ -265,6 +265,99 @@ __device__ __forceinline__ int lds_cholesky(double *A, int l)
     return bad;
 }
 
+// -------------------------------------------------------------------------------------
+// Blocked variant (block size 3), same input / output convention as lds_cholesky.  The unblocked
+// form is a chain of N steps, each with three dependent LDS round trips (row prefix, broadcast of
+// the pivot, write of the new column) that nothing overlaps; here every lane factors the 3 x 3
+// diagonal block redundantly in registers, so there is one round trip per block:
+//   D = A[J,J] - L[J,:j0] L[J,:j0]^T  (all lanes, from the LDS rows of J)      D = Ld Ld^T
+//   lane i: t = A[i,J] - L[i,:j0] L[J,:j0]^T (own row in registers),  L[i,J] = t Ld^-T
+// -------------------------------------------------------------------------------------
+template <int N, int LD, int G, int RSQ_ITERS = 1>
+__device__ __forceinline__ int lds_cholesky_blocked(double *A, int l)
+{
+    constexpr int NB = 3;
+    double row[N];
+    const bool act = l < N;
+    const int i = act ? l : 0;
+#pragma unroll
+    for (int k = 0; k + 1 < N; k += 2) {
+        const double2 v = lds_pair(A + i * LD + k);
+        row[k] = v.x; row[k + 1] = v.y;
+    }
+    if (N & 1) row[N - 1] = A[i * LD + N - 1];
+    int bad = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < N; j0 += NB) {
+        const int nb = (N - j0 < NB) ? (N - j0) : NB;       // constant after unrolling
+        // Schur complement of the diagonal block (lower triangle) and of the own row, sharing the reads of rows J
+        double d[NB][NB], t[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            if (r < nb) {
+                t[r] = row[j0 + r];
+#pragma unroll
+                for (int c = 0; c <= r; ++c) d[r][c] = A[(j0 + r) * LD + j0 + c];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < j0; k += 2) {                    // rows of J, two columns per 16-byte read
+            const bool two = k + 1 < j0;
+            double lj[NB], lj1[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                if (r < nb) {
+                    if (two) { const double2 v = lds_pair(A + (j0 + r) * LD + k); lj[r] = v.x; lj1[r] = v.y; }
+                    else { lj[r] = A[(j0 + r) * LD + k]; lj1[r] = 0.0; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                if (r < nb) {
+                    t[r] = __builtin_fma(-row[k], lj[r], t[r]);
+                    if (two) t[r] = __builtin_fma(-row[k + 1], lj1[r], t[r]);
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) {
+                        d[r][c] = __builtin_fma(-lj[r], lj[c], d[r][c]);
+                        if (two) d[r][c] = __builtin_fma(-lj1[r], lj1[c], d[r][c]);
+                    }
+                }
+            }
+        }
+        // factor the block in registers (reciprocal diagonal), solve the own row against it
+        double rd[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            if (c < nb) {
+                double p = d[c][c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) p = __builtin_fma(-d[c][k], d[c][k], p);
+                if (!(p > 0.0) && !bad) bad = j0 + c + 1;
+                rd[c] = fast_rsqrt<RSQ_ITERS>(p);
+#pragma unroll
+                for (int r = c + 1; r < NB; ++r) {
+                    if (r < nb) {
+                        double q = d[r][c];
+#pragma unroll
+                        for (int k = 0; k < c; ++k) q = __builtin_fma(-d[r][k], d[c][k], q);
+                        d[r][c] = q * rd[c];                    // Ld[r][c]
+                    }
+                }
+                double x = t[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) x = __builtin_fma(-row[j0 + k], d[c][k], x);
+                row[j0 + c] = x * rd[c];                        // L[i][j0 + c] (meaningful for i > j0 + c; == Ld for i in J)
+            }
+        }
+        // column block to LDS: L below the diagonal, 1/L[j][j] on it
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+            if (c < nb && act && l >= j0 + c) A[i * LD + j0 + c] = (l == j0 + c) ? rd[c] : row[j0 + c];
+        __syncthreads();
+    }
+    return bad;
+}
+
 // x <- L^-1 x (forward) and x <- L^-T x (backward); L as left by lds_cholesky (row-major).
 template <int N, int LD>
 __device__ __forceinline__ void lds_forward(const double *L, double (&x)[N])
@@ -684,7 +777,9 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
         PA_MARK("S4");
         double *LG = S + C::oST + 1 + LD;        // stiff[1:,1:], symmetric: row-major == column-major
         int bad = 0;
-        if (!(a.ablate & 8u)) bad = lds_cholesky<NR, LD, G>(LG, l);
+        // blocked form where its extra registers are free (measured: -3 % at k = 1; +4 % at k = 2, where it
+        // pushes the kernel into spills)
+        if (!(a.ablate & 8u)) bad = NR <= 6 ? lds_cholesky_blocked<NR, LD, G>(LG, l) : lds_cholesky<NR, LD, G>(LG, l);
         if (!(a.ablate & 16u)) lds_forward<NR, LD>(LG, col);
         // The trace columns are formed only now (not next to the gr_rhs columns in S3b): they stay
         // out of the register budget of the factorization.  They read the face tables of region Q,
