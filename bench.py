@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--workload", default="quad1024_k2", choices=sorted(WORKLOADS))
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "none"],
                     help="N>1 only: all_gather of the condensed face-dof blocks at the end of every step")
+    ap.add_argument("--chunks", type=int, default=4,
+                    help="N>1 only: the local rows are processed in this many pieces; the all_gather of a piece overlaps the kernels of the next")
     ap.add_argument("--backend", default=os.environ.get("PA_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl = RCCL, one rank per GPU (what the driver runs); gloo = rehearsal of the N>1 code path with "
                          "several ranks sharing the visible GPU(s) and a host-staged exchange (numbers not comparable)")
@@ -166,7 +168,7 @@ def main():
     import torch.distributed as dist
     import proton_amd as pa
     from proton_amd.batch import BatchAssembler
-    from proton_amd.partition import CondensedExchange, cell_counts, condensed_per_cell, row_partition
+    from proton_amd.partition import ChunkedExchange, condensed_per_cell, row_partition
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -218,30 +220,43 @@ def main():
     exchange = world > 1 and args.exchange == "allgather"
     if exchange:
         nf = 4 * sz.fbs
-        ex = CondensedExchange(cell_counts(N, N, world), condensed_per_cell(sz.fbs, packed=True), rank, dev, host_staged=rehearsal)
-        S_view, g_view = ex.local_S_g(nf)
+        ex = ChunkedExchange(N, world, rank, condensed_per_cell(sz.fbs, packed=True), dev, args.chunks, host_staged=rehearsal)
 
     if cut:
         cut_lc = torch.empty((max(asm.ncut, 1), sz.msize, sz.msize), dtype=torch.float64, device=dev)
         cut_rhs = torch.empty((max(asm.ncut, 1), sz.cbs), dtype=torch.float64, device=dev)
 
-    k_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    k_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    nchunks = ex.chunks if exchange else 1
+    k_start = [[torch.cuda.Event(enable_timing=True) for _ in range(nchunks)] for _ in range(args.steps)]
+    k_stop = [[torch.cuda.Event(enable_timing=True) for _ in range(nchunks)] for _ in range(args.steps)]
 
     def step(i=None):
-        if i is not None:
-            k_start[i].record()
-        asm.local_ops(w["cd"], w["fd"], quad, stab, want=(), out=out)
-        if i is not None:
-            k_stop[i].record()
-        asm.cell_rhs(w["cd"], w["fn"], quad, dinc=w["dinc"], out=rhs)
-        if cut and asm.ncut:
-            asm.ctx.cut_local_ops(w["fd"], asm.level_set, pa.capi.LOC_NEGATIVE, w["fn"], 2, None, None, None,
-                                  cut_lc.data_ptr(), cut_rhs.data_ptr(), None)
-            asm.ctx.cut_merge(w["fd"], pa.capi.LOC_NEGATIVE, cut_lc.data_ptr(), cut_rhs.data_ptr(), lc.data_ptr(), rhs.data_ptr())
-        if exchange:
-            asm.ctx.static_condensation_packed(di, n_local, lc.data_ptr(), rhs.data_ptr(), S_view.data_ptr(), g_view.data_ptr(), None)
-            ex.exchange()
+        if not exchange:
+            if i is not None:
+                k_start[i][0].record()
+            asm.local_ops(w["cd"], w["fd"], quad, stab, want=(), out=out)
+            if i is not None:
+                k_stop[i][0].record()
+            asm.cell_rhs(w["cd"], w["fn"], quad, dinc=w["dinc"], out=rhs)
+            if cut and asm.ncut:
+                asm.ctx.cut_local_ops(w["fd"], asm.level_set, pa.capi.LOC_NEGATIVE, w["fn"], 2, None, None, None,
+                                      cut_lc.data_ptr(), cut_rhs.data_ptr(), None)
+                asm.ctx.cut_merge(w["fd"], pa.capi.LOC_NEGATIVE, cut_lc.data_ptr(), cut_rhs.data_ptr(), lc.data_ptr(), rhs.data_ptr())
+            return
+        # N > 1: piece by piece; the collective of piece k overlaps the kernels of piece k + 1
+        for k in range(ex.chunks):
+            first, n = ex.piece_cells(k)
+            if i is not None:
+                k_start[i][k].record()
+            asm.ctx.local_ops(di, quad, stab, first, n, None, None, None, lc[first:first + n].data_ptr(), None)
+            if i is not None:
+                k_stop[i][k].record()
+            asm.ctx.cell_rhs(w["cd"], w["dinc"], quad, w["fn"], first, n, rhs[first:first + n].data_ptr(), None)
+            S_view, g_view = ex.local_S_g(k, nf)
+            asm.ctx.static_condensation_packed(di, n, lc[first:first + n].data_ptr(), rhs[first:first + n].data_ptr(),
+                                               S_view.data_ptr(), g_view.data_ptr(), None)
+            ex.exchange_async(k)
+        ex.wait()
 
     for _ in range(args.warmup):
         step()
@@ -258,7 +273,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    kern_ms = sum(a.elapsed_time(b) for a, b in zip(k_start, k_stop)) / args.steps
+    kern_ms = sum(a.elapsed_time(b) for sa, sb in zip(k_start, k_stop) for a, b in zip(sa, sb)) / args.steps
     t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

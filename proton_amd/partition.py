@@ -80,3 +80,45 @@ class CondensedExchange:
     def gathered(self, r):
         """view of rank r's block [counts[r], per_cell] after exchange()"""
         return self.recv[r * self.slot: r * self.slot + self.counts[r] * self.per_cell].view(self.counts[r], self.per_cell)
+
+
+class ChunkedExchange:
+    """The same exchange in `chunks` pieces of the local cell rows, so that the all_gather of one
+    piece runs (asynchronously, on the collective's own stream) while the kernels of the next piece
+    run.  Every piece is a CondensedExchange over the cells of that piece on every rank; pieces
+    are contiguous row blocks of the rank's slab (row_partition of the local rows)."""
+
+    def __init__(self, N, world, rank, per_cell, device, chunks, dtype=torch.float64, host_staged=False):
+        self.N, self.world, self.rank, self.per_cell = N, world, rank, per_cell
+        rows = [row_partition(N, world, r) for r in range(world)]
+        self.chunks = max(1, min(chunks, min(b - a for a, b in rows)))
+        # piece k of rank r: local rows [lo, hi) of its slab
+        self.pieces = [[row_partition(b - a, self.chunks, k) for k in range(self.chunks)] for a, b in rows]
+        self.ex = [CondensedExchange([(self.pieces[r][k][1] - self.pieces[r][k][0]) * N for r in range(world)], per_cell, rank,
+                                     device, dtype, host_staged) for k in range(self.chunks)]
+        self.pending = []
+
+    def piece_cells(self, k):
+        """(first local cell, number of cells) of piece k on this rank"""
+        lo, hi = self.pieces[self.rank][k]
+        return lo * self.N, (hi - lo) * self.N
+
+    def local_S_g(self, k, nf):
+        return self.ex[k].local_S_g(nf)
+
+    def exchange_async(self, k):
+        e = self.ex[k]
+        if e.world == 1 or e.host_staged:
+            e.exchange()
+        else:
+            self.pending.append(dist.all_gather_into_tensor(e.recv, e.send, async_op=True))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def gathered_S_g(self, r, nf):
+        """rank r's blocks in its local cell order: concatenation over the pieces (copies)"""
+        parts = [self.ex[k].gathered_S_g(r, nf) for k in range(self.chunks)]
+        return torch.cat([p[0] for p in parts], dim=0), torch.cat([p[1] for p in parts], dim=0)

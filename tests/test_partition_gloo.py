@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from proton_amd.partition import CondensedExchange, cell_counts, condensed_per_cell, row_partition, unpack_symmetric
+from proton_amd.partition import ChunkedExchange, CondensedExchange, cell_counts, condensed_per_cell, row_partition, unpack_symmetric
 
 
 def test_row_partition_covers_all_rows():
@@ -97,3 +97,55 @@ def test_two_rank_exchange_matches_single_process(N, cd, fd, packed):
         else:
             assert np.array_equal(results[r][0], refS)   # every rank holds the full set, in global cell order
         assert np.array_equal(results[r][1], refg)
+
+
+def _chunk_worker(rank, world, port, N, cd, fd, chunks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_lib as o
+        di = o.degrees(cd, fd)
+        nf = 4 * di.fbs
+        ex = ChunkedExchange(N, world, rank, condensed_per_cell(di.fbs), torch.device("cpu"), chunks)
+        r0, r1 = row_partition(N, world, rank)
+        covered = 0
+        for k in range(ex.chunks):                       # the bench's loop: piece k computed, its gather started
+            first, n = ex.piece_cells(k)
+            assert first == covered
+            covered += n
+            Sb, gb = _condensed_blocks(N, cd, fd, r0 * N + first, n)
+            S_view, g_view = ex.local_S_g(k, nf)
+            S_view.copy_(torch.from_numpy(Sb))
+            g_view.copy_(torch.from_numpy(gb))
+            ex.exchange_async(k)
+        assert covered == (r1 - r0) * N
+        ex.wait()
+        fullS = torch.cat([ex.gathered_S_g(r, nf)[0] for r in range(world)], dim=0).numpy()
+        fullg = torch.cat([ex.gathered_S_g(r, nf)[1] for r in range(world)], dim=0).numpy()
+        q.put((rank, (fullS, fullg)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,chunks", [(7, 3), (5, 8)])
+def test_chunked_overlapped_exchange_matches_single_process(N, chunks):
+    """the N > 1 step of bench.py: pieces of the local rows, asynchronous all_gather per piece (uneven pieces,
+    more pieces asked for than rows available)"""
+    cd, fd = 2, 1
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, N, cd, fd, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    refS, refg = _condensed_blocks(N, cd, fd, 0, N * N)
+    for r in range(world):
+        assert np.array_equal(results[r][0], refS) and np.array_equal(results[r][1], refg)
