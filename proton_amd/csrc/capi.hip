@@ -19,7 +19,8 @@
 #include "quad_tables.hpp"
 
 // ---- registry of instantiated kernels (one getter per translation unit, see pa_configs.def) ----
-#define PA_CONFIG(cd, fd, q, gmin) extern "C" const pa::KernelEntry *pa_entries_##cd##_##fd##_##q(int *count);
+#define PA_CONFIG(cd, fd, q, gmin) \
+    extern "C" __attribute__((visibility("hidden"))) const pa::KernelEntry *pa_entries_##cd##_##fd##_##q(int *count);
 #include "pa_configs.def"
 #undef PA_CONFIG
 

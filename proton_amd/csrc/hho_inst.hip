@@ -29,7 +29,8 @@ static const pa::KernelEntry k_entries[] = {
 
 #define PA_FN2(cd, fd, q) pa_entries_##cd##_##fd##_##q
 #define PA_FN(cd, fd, q) PA_FN2(cd, fd, q)
-extern "C" const pa::KernelEntry *PA_FN(PA_CD, PA_FD, PA_QUAD)(int *count)
+// internal to the library (the registry of capi.hip): not part of the exported C ABI
+extern "C" __attribute__((visibility("hidden"))) const pa::KernelEntry *PA_FN(PA_CD, PA_FD, PA_QUAD)(int *count)
 {
     *count = (int)(sizeof(k_entries) / sizeof(k_entries[0]));
     return k_entries;
