@@ -247,6 +247,17 @@ int pa_obstacle_take_local_data_batch(pa_context *ctx, pa_degree_info di, size_t
 int pa_csr_from_triplets(pa_context *ctx, size_t nslots, const int32_t *d_rows, const int32_t *d_cols, const double *d_vals,
                          size_t nrows, int64_t *d_rowptr, int32_t *d_colind, double *d_values, size_t *nnz);
 
+/* conjugated_gradient(A, b, x, cg_params) (src/core/core_bits/solver_cg.hpp:45-144; the solver of
+ * run_cuthho_interface, cuthho_square.cpp:1737-1743) on the CSR matrix of pa_csr_from_triplets.  Same
+ * recurrences and exit tests, in the reference's order: *exit_reason = 0 converged (relative residual
+ * below convergence_threshold), 2 max_iter reached (iter > max_iter), 1 diverged (relative residual above
+ * divergence_threshold).  apply_preconditioner: Jacobi.  x starts from zero (solver_cg.hpp:73).  The dot
+ * products are tree reductions, not Eigen's sequential sums: iterates agree to rounding, not bitwise. */
+int pa_conjugated_gradient(pa_context *ctx, size_t nrows, const int64_t *d_rowptr, const int32_t *d_colind,
+                           const double *d_values, const double *d_b, double *d_x,
+                           double convergence_threshold, double divergence_threshold, size_t max_iter,
+                           int apply_preconditioner, int32_t *exit_reason, size_t *iterations, double *relative_residual);
+
 /* ---- cutHHO (fictitious domain, `cuthho_square -f`) -----------------------------------------
  * circle_level_set / line_level_set, apps/cuthho/cuthho_square.cpp:56-124 */
 typedef struct { int32_t kind; double radius, alpha, beta, cut_y; } pa_level_set;   /* kind 0 circle, 1 line */

@@ -1,7 +1,7 @@
 """Build libproton_amd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
 One translation unit per (cell degree, face degree, quadrature kind) listed in
-csrc/pa_configs.def, compiled in parallel, plus csrc/capi.hip and csrc/csr.hip; linked into
+csrc/pa_configs.def, compiled in parallel, plus csrc/capi.hip, csrc/csr.hip and csrc/solver.hip; linked into
 proton_amd/lib/libproton_amd.so.  hipcc cross-compiles without a GPU.
 """
 import concurrent.futures
@@ -63,7 +63,7 @@ def build(force=False, verbose=False, jobs=None):
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
             todo.append((os.path.join(CSRC, "hho_inst.hip"), obj,
                          ["-DPA_CD=%d" % cd, "-DPA_FD=%d" % fd, "-DPA_QUAD=%d" % q, "-DPA_GMIN=%d" % gmin]))
-    for unit in ("capi", "csr"):
+    for unit in ("capi", "csr", "solver"):
         unit_obj = os.path.join(OBJ_DIR, unit + ".o")
         objs.append(unit_obj)
         if force or not os.path.exists(unit_obj) or os.path.getmtime(unit_obj) < newest:

@@ -136,6 +136,13 @@ class BatchAssembler:
                                          colind.data_ptr(), values.data_ptr())
         return rowptr, colind[:nnz], values[:nnz]
 
+    def conjugated_gradient(self, rowptr, colind, values, b, tol=1e-9, div=100.0, max_iter=1000, precond=True):
+        """solver_cg.hpp:63-144 on the device -> (x, exit_reason, iterations, relative residual)"""
+        x = torch.empty_like(b)
+        reason, iters, rr = self.ctx.conjugated_gradient(b.numel(), rowptr.data_ptr(), colind.data_ptr(), values.data_ptr(),
+                                                         b.data_ptr(), x.data_ptr(), tol, div, max_iter, precond)
+        return x, reason, iters, rr
+
     def take_local_data(self, cd, fd, solution, g=None, first=0, n=None):
         """assembler::take_local_data (hho.hpp:408-449) for cells [first, first+n) -> n x msize."""
         di, _ = capi.degree_info(cd, fd)

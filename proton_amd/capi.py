@@ -25,7 +25,7 @@ EXPORTS = [
     "pa_local_ops_batch", "pa_cell_rhs_batch", "pa_cell_quadrature_points",
     "pa_static_condensation_batch", "pa_static_condensation_packed_batch", "pa_local_ops_launch_info",
     "pa_mesh_set_faces", "pa_assembler_query", "pa_dirichlet_data_batch", "pa_face_quadrature_points",
-    "pa_triplets_batch", "pa_csr_from_triplets", "pa_take_local_data_batch", "pa_project_function_batch", "pa_energy_form_batch",
+    "pa_triplets_batch", "pa_csr_from_triplets", "pa_conjugated_gradient", "pa_take_local_data_batch", "pa_project_function_batch", "pa_energy_form_batch",
     "pa_obstacle_tables", "pa_obstacle_triplets_batch", "pa_obstacle_expand_solution",
     "pa_obstacle_take_local_data_batch",
     "pa_cut_preprocess", "pa_cut_query", "pa_cut_local_ops_batch", "pa_cut_merge",
@@ -128,6 +128,8 @@ def lib():
     L.pa_face_quadrature_points.argtypes = [vp, C.c_int, dp]
     L.pa_triplets_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp, dp, dp, dp, dp, dp]
     L.pa_csr_from_triplets.argtypes = [vp, sz, dp, dp, dp, sz, dp, dp, dp, C.POINTER(sz)]
+    L.pa_conjugated_gradient.argtypes = [vp, sz, dp, dp, dp, dp, dp, C.c_double, C.c_double, sz, C.c_int,
+                                         C.POINTER(C.c_int32), C.POINTER(sz), C.POINTER(C.c_double)]
     L.pa_take_local_data_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp]
     L.pa_project_function_batch.argtypes = [vp, DegreeInfo, C.c_int, C.c_int, C.c_int, dp, dp, sz, sz, dp, dp]
     L.pa_energy_form_batch.argtypes = [vp, DegreeInfo, sz, dp, dp, dp, dp]
@@ -265,6 +267,12 @@ class Context:
         self._ck(self._L.pa_csr_from_triplets(self.h, nslots, rows, cols, vals, nrows, rowptr, colind, values, C.byref(nnz)),
                  "pa_csr_from_triplets")
         return nnz.value
+
+    def conjugated_gradient(self, nrows, rowptr, colind, values, b, x, tol=1e-9, div=100.0, max_iter=1000, precond=True):
+        reason, iters, rr = C.c_int32(0), C.c_size_t(0), C.c_double(0.0)
+        self._ck(self._L.pa_conjugated_gradient(self.h, nrows, rowptr, colind, values, b, x, tol, div, max_iter, int(precond),
+                                                C.byref(reason), C.byref(iters), C.byref(rr)), "pa_conjugated_gradient")
+        return reason.value, iters.value, rr.value
 
     def take_local_data(self, di, first, n, solution, g, out):
         self._ck(self._L.pa_take_local_data_batch(self.h, di, first, n, solution, g, out), "pa_take_local_data_batch")

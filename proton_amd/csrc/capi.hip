@@ -60,6 +60,12 @@ hipError_t csr_from_triplets(hipStream_t stream, size_t n, const int32_t *d_rows
                              size_t nrows, int64_t *d_rowptr, int32_t *d_colind, double *d_values, size_t *nnz_out);   // csr.hip
 }
 
+namespace pa {
+hipError_t conjugated_gradient(hipStream_t stream, size_t n, const int64_t *rowptr, const int32_t *colind, const double *values,
+                               const double *b, double *x, double convergence_threshold, double divergence_threshold,
+                               size_t max_iter, int precond, int *exit_reason, size_t *iterations, double *relative_residual);   // solver.hip
+}
+
 struct pa_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -573,6 +579,19 @@ int pa_csr_from_triplets(pa_context *ctx, size_t nslots, const int32_t *d_rows, 
     if (!ctx || !d_rowptr || (nslots && (!d_rows || !d_cols || !d_vals || !d_colind || !d_values))) return PA_ERR_INVALID_ARG;
     if (nslots >= ((size_t)1 << 31) || nrows >= ((size_t)1 << 31)) return PA_ERR_INVALID_ARG;
     PA_HIP(ctx, pa::csr_from_triplets(ctx->stream, nslots, d_rows, d_cols, d_vals, nrows, d_rowptr, d_colind, d_values, nnz));
+    return PA_OK;
+}
+
+int pa_conjugated_gradient(pa_context *ctx, size_t nrows, const int64_t *d_rowptr, const int32_t *d_colind, const double *d_values,
+                           const double *d_b, double *d_x, double convergence_threshold, double divergence_threshold,
+                           size_t max_iter, int apply_preconditioner, int32_t *exit_reason, size_t *iterations,
+                           double *relative_residual)
+{
+    if (!ctx || !d_rowptr || (nrows && (!d_colind || !d_values || !d_b || !d_x))) return PA_ERR_INVALID_ARG;
+    int reason = 0;
+    PA_HIP(ctx, pa::conjugated_gradient(ctx->stream, nrows, d_rowptr, d_colind, d_values, d_b, d_x, convergence_threshold,
+                                        divergence_threshold, max_iter, apply_preconditioner, &reason, iterations, relative_residual));
+    if (exit_reason) *exit_reason = reason;
     return PA_OK;
 }
 

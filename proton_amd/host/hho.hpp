@@ -12,6 +12,7 @@
 //   assembler / make_assembler              src/methods/hho_bits/hho.hpp:252-463
 //   obstacle_assembler / take_local_data    src/methods/hho_bits/hho.hpp:471-789
 //   project_function                        src/core/core_bits/utils.hpp:199-227
+//   cg_params / conjugated_gradient         src/core/core_bits/solver_cg.hpp:38-144
 // Everything numerical is computed on the GPU through the C ABI of include/proton_amd.h
 // (libproton_amd.so); there is no CPU fallback -- a missing library or GPU throws.
 //
@@ -855,6 +856,44 @@ template <typename Mesh>
 auto make_assembler(const Mesh &msh, hho_degree_info hdi)
 {
     return assembler<Mesh>(msh, hdi);
+}
+
+// solver_cg.hpp:38-144: the reference's (optionally Jacobi-preconditioned) conjugate gradient,
+// run on the device over the CSR matrix (pa_conjugated_gradient)
+enum class cg_exit_reason { CONVERGED, DIVERGED, MAX_ITER_REACHED };
+
+template <typename T>
+struct cg_params {
+    T convergence_threshold, divergence_threshold;
+    size_t max_iter;
+    bool verbose, apply_preconditioner;
+    std::string histfile;
+    cg_params() : convergence_threshold(1e-9), divergence_threshold(100), max_iter(1000), verbose(false), apply_preconditioner(false) {}
+};
+
+template <typename T>
+cg_exit_reason conjugated_gradient(const proton_amd::sparse_matrix<T> &A, const std::vector<T> &b, std::vector<T> &x,
+                                   const cg_params<T> &parms = cg_params<T>(), size_t *iterations = nullptr)
+{
+    auto &dev = proton_amd::device::instance();
+    const size_t n = A.rows(), nnz = A.nonZeros();
+    proton_amd::device_buffer<int64_t> d_rowptr(n + 1);
+    proton_amd::device_buffer<int32_t> d_colind(nnz + 1);
+    proton_amd::device_buffer<double> d_values(nnz + 1), d_b(n + 1), d_x(n + 1);
+    d_rowptr.upload(A.rowptr.data(), n + 1);
+    if (nnz) { d_colind.upload(A.colind.data(), nnz); d_values.upload(A.values.data(), nnz); }
+    if (n) d_b.upload(b.data(), n);
+    int32_t reason = 0;
+    size_t iters = 0;
+    double rr = 0.0;
+    dev.check(pa_conjugated_gradient(dev.ctx(), n, d_rowptr.get(), d_colind.get(), d_values.get(), d_b.get(), d_x.get(),
+                                     parms.convergence_threshold, parms.divergence_threshold, parms.max_iter,
+                                     parms.apply_preconditioner ? 1 : 0, &reason, &iters, &rr), "pa_conjugated_gradient");
+    x.resize(n);
+    if (n) d_x.download(x.data(), n);
+    if (parms.verbose) std::cout << " -> Iteration " << iters << ", rr = " << rr << std::endl;
+    if (iterations) *iterations = iters;
+    return reason == 0 ? cg_exit_reason::CONVERGED : reason == 1 ? cg_exit_reason::DIVERGED : cg_exit_reason::MAX_ITER_REACHED;
 }
 
 // hho.hpp:471-751.  Unknowns: cells outside the active set, then the non-Dirichlet faces, then one

@@ -3,7 +3,7 @@
 // make_rhs / assembler.assemble, finalize, Jacobi-PCG solve (the reference's own solver,
 // src/core/core_bits/solver_cg.hpp:63-144, restated for the CSR type), L2 error and rates.
 // Compiled against proton_amd/host/hho.hpp only: no Eigen, no HIP headers.
-//   usage: convergence_driver <k> <min_N> <steps> [batched]
+//   usage: convergence_driver <k> <min_N> <steps> [batched|device]   (device: batched assembly, device CSR, device PCG)
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -54,6 +54,7 @@ int main(int argc, char **argv)
     const size_t min_N = argc > 2 ? std::atoi(argv[2]) : 4;
     const size_t steps = argc > 3 ? std::atoi(argv[3]) : 3;
     const bool batched = argc > 4;
+    const bool device_solve = argc > 4 && std::string(argv[4]) == "device";
 
     auto rhs_fun = [](const mesh_type::point_type &pt) -> RealType {      // convergence_test.cpp:100-102
         return 2.0 * M_PI * M_PI * std::sin(M_PI * pt.x()) * std::sin(M_PI * pt.y());
@@ -86,7 +87,14 @@ int main(int argc, char **argv)
         const double t_asm = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
         std::vector<RealType> sol;
-        const size_t iters = pcg(assembler.LHS, assembler.RHS, sol, 1e-12, 3 * assembler.LHS.rows());
+        size_t iters = 0;
+        if (device_solve) {                                                 // the reference's conjugated_gradient, on the device
+            cg_params<RealType> cgp;
+            cgp.convergence_threshold = 1e-12; cgp.max_iter = 3 * assembler.LHS.rows(); cgp.apply_preconditioner = true;
+            if (conjugated_gradient(assembler.LHS, assembler.RHS, sol, cgp, &iters) != cg_exit_reason::CONVERGED) return 2;
+        } else {
+            iters = pcg(assembler.LHS, assembler.RHS, sol, 1e-12, 3 * assembler.LHS.rows());
+        }
 
         // errors_int, convergence_test.cpp:254-268: the device supplies the quadrature points
         RealType err = 0.0;

@@ -169,3 +169,41 @@ def test_device_csr_edge_cases(asm):
         got_rows = np.repeat(np.arange(50), np.diff(rp))
         assert [(int(a), int(b)) for a, b in zip(got_rows, ci)] == keys
         assert np.array_equal(va, np.array([want[k] for k in keys]))
+
+
+def test_device_conjugated_gradient(asm):
+    """pa_conjugated_gradient (solver_cg.hpp:63-144) on the device CSR of a Poisson system: solution equals the
+    sparse direct solve, iteration count close to the same recurrences run in numpy, exit reasons in the reference's order."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import torch
+    N, cd, fd = 16, 2, 1
+    lc, rhs, g, r, c, v, rr, rv = gpu_assembly(asm, N, cd, fd)
+    info = asm.assembler_info(cd, fd)
+    n = info.system_size
+    rowptr, colind, values = asm.csr_from_triplets(r, c, v, n)
+    b = torch.zeros(n, dtype=torch.float64, device=asm.device)
+    ok = rr.reshape(-1) >= 0
+    b.index_add_(0, rr.reshape(-1)[ok].long(), rv.reshape(-1)[ok])
+    x, reason, iters, relres = asm.conjugated_gradient(rowptr, colind, values, b, tol=1e-12, max_iter=3 * n, precond=True)
+    asm.synchronize()
+    A = sp.csr_matrix((values.cpu().numpy(), colind.cpu().numpy(), rowptr.cpu().numpy()), shape=(n, n))
+    ref = spla.spsolve(A.tocsc(), b.cpu().numpy())
+    assert reason == 0 and relres < 1e-12
+    assert np.abs(x.cpu().numpy() - ref).max() < 1e-9 * np.abs(ref).max()
+    # the same recurrences in numpy (Eigen's sequential sums replaced by numpy's): same iteration count +- a few
+    bb = b.cpu().numpy(); iA = 1.0 / A.diagonal()
+    xx = np.zeros(n); rres = bb.copy(); d = iA * rres; nr0 = np.linalg.norm(rres); it = 0
+    while True:
+        y = A @ d; z = iA * rres; rho = rres @ z; alpha = rho / (d @ y)
+        xx += alpha * d; rres -= alpha * y
+        if np.linalg.norm(rres) / nr0 < 1e-12:
+            break
+        z = iA * rres; d = z + (rres @ z) / rho * d; it += 1
+    assert abs(it - iters) <= max(3, it // 50), (it, iters)
+    # max_iter exit: the reference stops when iter > max_iter (solver_cg.hpp:112-115)
+    x2, reason2, iters2, _ = asm.conjugated_gradient(rowptr, colind, values, b, tol=1e-30, max_iter=5, precond=True)
+    assert reason2 == 2 and iters2 == 6
+    # divergence threshold below the first relative residual: DIVERGED
+    x3, reason3, iters3, _ = asm.conjugated_gradient(rowptr, colind, values, b, tol=1e-30, div=1e-6, max_iter=50, precond=False)
+    assert reason3 == 1 and iters3 == 0

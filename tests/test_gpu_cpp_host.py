@@ -99,6 +99,9 @@ def test_batched_api_same_as_per_cell(driver):
     e1, _, _ = run(driver, 1, 8, 2)
     e2, _, _ = run(driver, 1, 8, 2, "batched")
     assert np.allclose(e1, e2, rtol=1e-8)
+    # device CSR + the reference's conjugated_gradient on the device
+    e4, _, out = run(driver, 1, 8, 2, "device")
+    assert np.allclose(e1, e4, rtol=1e-7), out
     # config 1 of BASELINE.json: 32x32 k=1 (plumbing), batched
     e3, r3, out = run(driver, 1, 16, 2, "batched")
     assert r3[-1] > 2.7 and "N 32" in out
