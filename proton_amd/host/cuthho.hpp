@@ -274,3 +274,158 @@ make_hho_laplacian_interface(const cuthho_poly_mesh<T> &msh, const typename cuth
     const size_t cc = (size_t)msh.cut_index[offset(msh, cl)], m2 = 2 * (size_t)cache.sz.msize, n2 = 2 * (size_t)cache.sz.rbs;
     return std::make_pair(proton_amd::copy_cell<T>(cache.oper, cc, n2, m2), proton_amd::copy_cell<T>(cache.data, cc, m2, m2));
 }
+
+// make_rhs(msh, cl, degree, where, f)  src/methods/cuthho_bits/cuthho_utils.hpp:65-84: the source term
+// over the `where` part of a cell (no boundary term).  Cut cells: the library's cut quadrature with
+// host-sampled values, sums on the device (the Nitsche part of pa_cut_rhs_sampled_batch gets zeros).
+template <typename T, typename Function>
+proton_amd::dense_matrix<T> make_rhs(const cuthho_poly_mesh<T> &msh, const typename cuthho_poly_mesh<T>::cell_type &cl, size_t degree,
+                                     element_location where, const Function &f)
+{
+    const size_t cbs = (degree + 2) * (degree + 1) / 2;
+    if (!is_cut(msh, cl)) return location(msh, cl) == where ? make_rhs(msh, cl, degree, f) : proton_amd::dense_matrix<T>(cbs, 1);
+    struct cached { const void *msh = nullptr, *fn = nullptr; size_t degree = 0; std::vector<double> rhs[2]; };
+    static cached cache;
+    hho_degree_info hdi(degree, degree - 1);
+    if (cache.msh != (const void *)&msh || cache.fn != (const void *)&f || cache.degree != degree) {
+        auto &dev = proton_amd::device::instance();
+        for (int side = 0; side < 2; ++side) {
+            auto &b = proton_amd::cut_batch<T>::get(msh, hdi, (element_location)side);
+            const size_t nq = b.cell_xyw.size() / 3, ni = b.ir_xyw.size() / 3;
+            std::vector<double> fv(nq + 1), zeros(ni + 1, 0.0);
+            for (size_t q = 0; q < nq; ++q) fv[q] = f(point<T, 2>(b.cell_xyw[3 * q], b.cell_xyw[3 * q + 1]));
+            proton_amd::device_buffer<double> d_f(nq + 1), d_z(ni + 1), d_r(msh.num_cut_cells * cbs + 1);
+            d_f.upload(fv.data(), nq + 1); d_z.upload(zeros.data(), ni + 1);
+            dev.check(pa_cut_rhs_sampled_batch(dev.ctx(), b.face_deg, &msh.level_set, side, d_f.get(), d_z.get(), d_r.get()),
+                      "pa_cut_rhs_sampled_batch");
+            cache.rhs[side].resize(msh.num_cut_cells * cbs);
+            if (!cache.rhs[side].empty()) d_r.download(cache.rhs[side].data(), cache.rhs[side].size());
+        }
+        cache.msh = (const void *)&msh; cache.fn = (const void *)&f; cache.degree = degree;
+    }
+    return proton_amd::copy_cell<T>(cache.rhs[(int)where], (size_t)msh.cut_index[offset(msh, cl)], cbs, 1);
+}
+
+// interface_assembler  apps/cuthho/cuthho_square.cpp:1091-1443: cut cells and cut faces own two
+// blocks of unknowns (negative side first).  Cut cells must not touch the Dirichlet boundary.
+template <typename Mesh>
+class interface_assembler {
+    using T = typename Mesh::coordinate_type;
+    hho_degree_info di;
+    proton_amd::face_numbering<Mesh> numbering;          // Dirichlet data of the boundary functor
+    std::vector<int64_t> cell_table, face_table;         // first block of each cell / non-Dirichlet face (-1: Dirichlet)
+    size_t num_all_cells = 0, num_other_faces = 0;
+    std::vector<std::tuple<int32_t, int32_t, T>> triplets;
+
+    size_t face_block(const Mesh &msh, size_t face_offset, size_t fbs, bool second) const
+    {
+        const size_t dup = (second && msh.face_tags[face_offset] == element_location::ON_INTERFACE) ? fbs : 0;     // :1319
+        return num_all_cells * numbering.cbs + (size_t)face_table[face_offset] * fbs + dup;
+    }
+
+  public:
+    proton_amd::sparse_matrix<T> LHS;
+    std::vector<T> RHS;
+
+    interface_assembler(const Mesh &msh, hho_degree_info hdi) : di(hdi), numbering(msh, hdi)
+    {
+        cell_table.resize(msh.cells.size());
+        for (size_t c = 0; c < msh.cells.size(); ++c) {                                    // :1142-1150
+            cell_table[c] = (int64_t)num_all_cells;
+            num_all_cells += msh.cell_tags[c] == element_location::ON_INTERFACE ? 2 : 1;
+        }
+        face_table.assign(msh.faces.size(), -1);
+        for (size_t f = 0; f < msh.faces.size(); ++f) {                                    // :1167-1178
+            if (numbering.compress[f] < 0) continue;
+            face_table[f] = (int64_t)num_other_faces;
+            num_other_faces += msh.face_tags[f] == element_location::ON_INTERFACE ? 2 : 1;
+        }
+        const size_t system_size = numbering.cbs * num_all_cells + numbering.fbs * num_other_faces;      // :1185
+        LHS.nrows = LHS.ncols = system_size;
+        RHS.assign(system_size, T(0));
+    }
+
+    // :1203-1269
+    template <typename Function>
+    void assemble(const Mesh &msh, const typename Mesh::cell_type &cl, const proton_amd::dense_matrix<T> &lhs,
+                  const proton_amd::dense_matrix<T> &rhs, const Function &dirichlet_bf)
+    {
+        if (location(msh, cl) == element_location::ON_INTERFACE) throw std::invalid_argument("UNcut cell expected.");
+        const size_t cbs = numbering.cbs, fbs = numbering.fbs, ms = cbs + 4 * fbs, c = offset(msh, cl);
+        const auto fids = proton_amd::face_offsets(msh, cl);
+        std::vector<int64_t> gidx(ms, -1);
+        std::vector<T> dir(ms, T(0));
+        for (size_t i = 0; i < cbs; ++i) gidx[i] = cell_table[c] * (int64_t)cbs + (int64_t)i;
+        for (size_t lf = 0; lf < 4; ++lf)
+            for (size_t k = 0; k < fbs; ++k) {
+                const size_t l = cbs + lf * fbs + k;
+                if (face_table[fids[lf]] >= 0) gidx[l] = (int64_t)(face_block(msh, fids[lf], fbs, false) + k);
+                else dir[l] = numbering.dirichlet_data(msh, dirichlet_bf)[fids[lf] * fbs + k];
+            }
+        for (size_t i = 0; i < ms; ++i) {
+            if (gidx[i] < 0) continue;
+            T moved = T(0);
+            for (size_t j = 0; j < ms; ++j) {
+                if (gidx[j] >= 0) triplets.emplace_back((int32_t)gidx[i], (int32_t)gidx[j], lhs(i, j));
+                else moved += lhs(i, j) * dir[j];
+            }
+            RHS[gidx[i]] -= moved;
+        }
+        for (size_t i = 0; i < cbs; ++i) RHS[gidx[i]] += rhs(i);
+    }
+
+    // :1271-1354: unknowns [cell-, cell+, faces-, faces+]
+    void assemble_cut(const Mesh &msh, const typename Mesh::cell_type &cl, const proton_amd::dense_matrix<T> &lhs,
+                      const proton_amd::dense_matrix<T> &rhs)
+    {
+        if (location(msh, cl) != element_location::ON_INTERFACE) throw std::invalid_argument("Cut cell expected.");
+        const size_t cbs = numbering.cbs, fbs = numbering.fbs, ms2 = 2 * (cbs + 4 * fbs), c = offset(msh, cl);
+        const auto fids = proton_amd::face_offsets(msh, cl);
+        std::vector<int64_t> gidx(ms2);
+        for (size_t i = 0; i < 2 * cbs; ++i) gidx[i] = cell_table[c] * (int64_t)cbs + (int64_t)i;
+        for (size_t pass = 0; pass < 2; ++pass)
+            for (size_t lf = 0; lf < 4; ++lf) {
+                if (face_table[fids[lf]] < 0) throw std::invalid_argument("Dirichlet boundary on cut cell not supported.");
+                for (size_t k = 0; k < fbs; ++k)
+                    gidx[2 * cbs + pass * 4 * fbs + lf * fbs + k] = (int64_t)(face_block(msh, fids[lf], fbs, pass == 1) + k);
+            }
+        if (lhs.rows() != ms2 || lhs.cols() != ms2) throw std::invalid_argument("interface_assembler::assemble_cut: local matrix size");
+        for (size_t i = 0; i < ms2; ++i)
+            for (size_t j = 0; j < ms2; ++j) triplets.emplace_back((int32_t)gidx[i], (int32_t)gidx[j], lhs(i, j));
+        for (size_t i = 0; i < 2 * cbs; ++i) RHS[gidx[i]] += rhs(i);
+    }
+
+    // :1356-1430.  Cell unknowns of the `where` side, then the four faces' unknowns of that side.  (The
+    // reference overwrites its face offsets with a formula that ignores the duplicated unknowns --
+    // quirk 11 of the survey; its driver only reads the cell part.  Here the face part is the intended one.)
+    template <typename Function>
+    proton_amd::dense_matrix<T> take_local_data(const Mesh &msh, const typename Mesh::cell_type &cl, const std::vector<T> &solution,
+                                                 const Function &dirichlet_bf, element_location where)
+    {
+        const size_t cbs = numbering.cbs, fbs = numbering.fbs, c = offset(msh, cl);
+        const bool second = where == element_location::IN_POSITIVE_SIDE;
+        if (location(msh, cl) == element_location::ON_INTERFACE && where != element_location::IN_NEGATIVE_SIDE && !second)
+            throw std::invalid_argument("Invalid location");
+        const size_t cell_SOL_offset = (size_t)cell_table[c] * cbs + ((second && location(msh, cl) == element_location::ON_INTERFACE) ? cbs : 0);
+        const auto fids = proton_amd::face_offsets(msh, cl);
+        proton_amd::dense_matrix<T> ret(cbs + 4 * fbs, 1);
+        for (size_t i = 0; i < cbs; ++i) ret(i) = solution[cell_SOL_offset + i];
+        for (size_t lf = 0; lf < 4; ++lf)
+            for (size_t k = 0; k < fbs; ++k)
+                ret(cbs + lf * fbs + k) = face_table[fids[lf]] < 0 ? numbering.dirichlet_data(msh, dirichlet_bf)[fids[lf] * fbs + k]
+                                                                   : solution[face_block(msh, fids[lf], fbs, second) + k];
+        return ret;
+    }
+
+    void finalize(void)
+    {
+        LHS.set_from_triplets(RHS.size(), triplets);
+        triplets.clear();
+    }
+};
+
+template <typename Mesh>
+auto make_interface_assembler(const Mesh &msh, hho_degree_info hdi)
+{
+    return interface_assembler<Mesh>(msh, hdi);
+}

@@ -189,6 +189,13 @@ class dense_matrix {
             for (size_t i = 0; i < r_; ++i) m(j, i) = (*this)(i, j);
         return m;
     }
+    // this.block(i0, j0, m.rows(), m.cols()) += m   (Eigen: lc.block(...) += ...)
+    void add_to_block(size_t i0, size_t j0, const dense_matrix &m)
+    {
+        assert(i0 + m.r_ <= r_ && j0 + m.c_ <= c_);
+        for (size_t j = 0; j < m.c_; ++j)
+            for (size_t i = 0; i < m.r_; ++i) (*this)(i0 + i, j0 + j) += m(i, j);
+    }
     dense_matrix block(size_t i0, size_t j0, size_t nr, size_t nc) const
     {
         dense_matrix m(nr, nc);

@@ -55,12 +55,24 @@ def test_cuthho_driver_reproduces_committed_results(cuthho_driver, k, N, ref):
     """apps/cuthho `-f` through the drop-in header proton_amd/host/cuthho.hpp (the reference's step
     functions, cut make_hho_laplacian / make_hho_cut_stabilization / make_rhs with host functors,
     cut integrate) reproduces the F.D. table of apps/cuthho/cuthho.xlsx (r = 4)."""
-    r = subprocess.run([cuthho_driver, str(k), str(N), "4"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([cuthho_driver, "-k", str(k), "-M", str(N), "-N", str(N), "-r", "4", "-f"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     m = re.search(r"cut_cells (\d+) .* energy_error ([0-9.e+-]+)", r.stdout)
     assert m and int(m.group(1)) > 0, r.stdout
     err = float(m.group(2))
     assert abs(err - ref) / ref < 6e-6, r.stdout
+
+
+@pytest.mark.parametrize("k,N,ref", [(0, 10, 0.285023), (1, 10, 2.01456e-2), (2, 20, 1.38029e-4)])
+def test_cuthho_driver_interface_problem(cuthho_driver, k, N, ref):
+    """`cuthho_square -i` through the drop-in header: make_hho_laplacian_interface, both cut stabilizations,
+    one-sided make_rhs, interface_assembler and the reference's conjugated_gradient (defaults of
+    run_cuthho_interface: threshold 1e-9, Jacobi) reproduce the Interface table of cuthho.xlsx."""
+    r = subprocess.run([cuthho_driver, "-k", str(k), "-M", str(N), "-N", str(N), "-r", "4", "-i"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"interface .* energy_error ([0-9.e+-]+)", r.stdout)
+    assert m, r.stdout
+    assert abs(float(m.group(1)) - ref) / ref < 6e-6, r.stdout
 
 
 @pytest.fixture(scope="module")
