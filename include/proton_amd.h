@@ -271,6 +271,17 @@ enum { PA_LOC_NEGATIVE = 0, PA_LOC_POSITIVE = 1, PA_LOC_ON_INTERFACE = 2 };     
  * search range") are returned as PA_ERR_INVALID_ARG with the text in pa_last_error(). */
 int pa_cut_preprocess(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
                       const pa_level_set *ls, int refsteps);
+/* The agglomeration branch of the same preprocessing (`-A`, cuthho_square.cpp:2039-2044): no node
+ * displacement.  The reference then only CLASSIFIES the cut cells (detect_cell_agglo_set); its
+ * agglomerate_cells is dead code (cuthho_square.cpp:1525-1621).  All operators of this library
+ * work on the resulting mesh as on the displaced one. */
+int pa_cut_preprocess_agglomeration(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y,
+                                    double max_y, const pa_level_set *ls, int refsteps);
+/* detect_cell_agglo_set (cuthho_geom.hpp:163-273, threshold 0.3): agglo_set ncells (host),
+ * 0 UNDEF, 1 T_OK, 2 T_KO_NEG, 3 T_KO_POS (cuthho_mesh.hpp's cell_agglo_set order), and
+ * make_neighbors_info (cuthho_geom.hpp:343-370; O(cells^2) there, closed form here): neighbors
+ * ncells x 8 cell ids sharing a point, ascending, -1 padded.  Either may be NULL. */
+int pa_cut_agglo_query(pa_context *ctx, int8_t *agglo_set, int32_t *neighbors);
 /* cell tags (element_location per cell) and, for cut cells, their index in the cut-cell batch
  * (-1 otherwise).  Host arrays of ncells entries; either may be NULL.  *ncut may be NULL. */
 int pa_cut_query(pa_context *ctx, size_t *ncut, int8_t *cell_location, int32_t *cut_index);

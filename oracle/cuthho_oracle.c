@@ -254,14 +254,81 @@ static int refine_interface_rec(cut_mesh *m, size_t c, const cut_level_set *ls, 
     return refine_interface_rec(m, c, ls, mid, max);
 }
 
-int cut_mesh_preprocess(cut_mesh *m, const cut_level_set *ls, int refsteps)
+static int preprocess(cut_mesh *m, const cut_level_set *ls, int refsteps, int displace);
+
+int cut_mesh_preprocess(cut_mesh *m, const cut_level_set *ls, int refsteps) { return preprocess(m, ls, refsteps, 1); }
+/* the agglomeration branch of cuthho_square.cpp:2039-2044 (-A): no node displacement */
+int cut_mesh_preprocess_agglomeration(cut_mesh *m, const cut_level_set *ls, int refsteps) { return preprocess(m, ls, refsteps, 0); }
+
+/* detect_cell_agglo_set cuthho_geom.hpp:163-273 */
+void cut_mesh_agglo_set(const cut_mesh *m, int8_t *agglo)
+{
+    const double threshold = 0.3;                                /* :170 */
+    for (size_t c = 0; c < m->nc; c++) {
+        agglo[c] = CUT_AGGLO_UNDEF;
+        const size_t *fcs = m->cell_faces + 4 * c;
+        const uint64_t *ids = m->ptids + 4 * c;
+        int cut[4];
+        double d[4][2];                                          /* d[n][0]: node n to the cut of face n-1, d[n][1]: to the cut of face n */
+        for (int i = 0; i < 4; i++) cut[i] = m->face_loc[fcs[i]] == CUT_ON_INTERFACE;
+        for (int n = 0; n < 4; n++)
+            for (int s = 0; s < 2; s++) {
+                size_t f = fcs[s == 0 ? (n == 0 ? 3 : n - 1) : n];
+                const double *p0 = &m->points[2 * m->faces[2 * f]], *p1 = &m->points[2 * m->faces[2 * f + 1]];
+                const double *pn = &m->points[2 * ids[n]], *ip = &m->face_ip[2 * f];
+                double ma = sqrt((p1[0] - p0[0]) * (p1[0] - p0[0]) + (p1[1] - p0[1]) * (p1[1] - p0[1]));
+                d[n][s] = sqrt((pn[0] - ip[0]) * (pn[0] - ip[0]) + (pn[1] - ip[1]) * (pn[1] - ip[1])) / ma;
+            }
+        for (int i = 0; i < 4; i++) {                            /* :243-252 -> agglo_set_single_node(n) :182-206 */
+            int f1 = i, f2 = (i + 1) % 4, n = (i + 1) % 4;
+            if (!(cut[f1] && cut[f2])) continue;
+            double da = d[n][0], db = d[n][1];
+            if ((da < db ? da : db) > threshold) agglo[c] = CUT_AGGLO_T_OK;
+            else agglo[c] = m->node_loc[ids[n]] == CUT_NEG ? CUT_AGGLO_T_KO_NEG : CUT_AGGLO_T_KO_POS;
+        }
+        for (int f1 = 0; f1 < 2; f1++) {                         /* :254-258 -> agglo_set_double_node(f1, f2) :208-241 */
+            int f2 = f1 + 2;
+            if (!(cut[f1] && cut[f2])) continue;
+            int n1 = f1, n2 = (f2 + 1) % 4;
+            double da = d[n1][1];                                /* node n1 against face f1 == n1 */
+            double db = d[n2][0];                                /* node n2 against face f2 == n2 - 1 */
+            double m1 = da > db ? da : db, m2 = (1 - da) > (1 - db) ? (1 - da) : (1 - db);
+            if ((m1 < m2 ? m1 : m2) > threshold) { agglo[c] = CUT_AGGLO_T_OK; continue; }
+            if (m->node_loc[ids[n1]] == CUT_NEG) agglo[c] = (m1 <= threshold) ? CUT_AGGLO_T_KO_NEG : CUT_AGGLO_T_KO_POS;
+            else agglo[c] = (m2 <= threshold) ? CUT_AGGLO_T_KO_NEG : CUT_AGGLO_T_KO_POS;
+        }
+    }
+}
+
+/* make_neighbors_info cuthho_geom.hpp:343-370, literally: all pairs, "share a point id" (O(cells^2)).
+ * neighbors: nc x 8, ascending, -1 padded. */
+void cut_mesh_neighbors(const cut_mesh *m, int32_t *neighbors)
+{
+    for (size_t i = 0; i < m->nc * 8; i++) neighbors[i] = -1;
+    for (size_t i = 0; i < m->nc; i++) {
+        int k = 0;
+        for (size_t j = 0; j < m->nc; j++) {
+            if (i == j) continue;
+            int share = 0;
+            for (int a = 0; a < 4; a++)
+                for (int b = 0; b < 4; b++)
+                    if (m->ptids[4 * i + a] == m->ptids[4 * j + b]) share = 1;
+            if (share && k < 8) neighbors[8 * i + k++] = (int32_t)j;
+        }
+    }
+}
+
+static int preprocess(cut_mesh *m, const cut_level_set *ls, int refsteps, int displace)
 {
     for (size_t n = 0; n < m->np; n++)                           /* detect_node_position :118-130 */
         m->node_loc[n] = cut_ls_eval(ls, m->points[2 * n], m->points[2 * n + 1]) < 0 ? CUT_NEG : CUT_POS;
     detect_cut_faces(m, ls);
-    int st = move_nodes(m);
-    if (st) return st;
-    detect_cut_faces(m, ls);                                     /* again, to update the intersection points :2048 */
+    int st = 0;
+    if (displace) {
+        st = move_nodes(m);
+        if (st) return st;
+        detect_cut_faces(m, ls);                                 /* again, to update the intersection points :2048 */
+    }
     st = detect_cut_cells(m, ls);
     if (st) return st;
     /* refine_interface :653-673 (levels == 0: the interface stays [p0, p1]) */

@@ -36,6 +36,16 @@ void cut_mesh_free(cut_mesh *m);
  * polygon, interface not found). */
 int cut_mesh_preprocess(cut_mesh *m, const cut_level_set *ls, int refsteps);
 
+/* the -A branch of cuthho_square.cpp:2039-2044: detect_node_position, detect_cut_faces,
+ * detect_cut_cells (no node displacement), refine_interface */
+int cut_mesh_preprocess_agglomeration(cut_mesh *m, const cut_level_set *ls, int refsteps);
+/* detect_cell_agglo_set cuthho_geom.hpp:163-273 (threshold 0.3): per cell, the reference's
+ * cell_agglo_set in its declaration order */
+enum { CUT_AGGLO_UNDEF = 0, CUT_AGGLO_T_OK = 1, CUT_AGGLO_T_KO_NEG = 2, CUT_AGGLO_T_KO_POS = 3 };
+void cut_mesh_agglo_set(const cut_mesh *m, int8_t *agglo);
+/* make_neighbors_info cuthho_geom.hpp:343-370 (all pairs of cells): nc x 8 ids, ascending, -1 padded */
+void cut_mesh_neighbors(const cut_mesh *m, int32_t *neighbors);
+
 size_t cut_mesh_num_points(const cut_mesh *m);
 size_t cut_mesh_num_cells(const cut_mesh *m);
 size_t cut_mesh_num_faces(const cut_mesh *m);

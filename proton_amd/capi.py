@@ -29,7 +29,7 @@ EXPORTS = [
     "pa_obstacle_tables", "pa_obstacle_triplets_batch", "pa_obstacle_expand_solution",
     "pa_obstacle_take_local_data_batch",
     "pa_cut_preprocess", "pa_cut_query", "pa_cut_local_ops_batch", "pa_cut_merge",
-    "pa_cut_query_tags", "pa_cut_quadrature_points", "pa_cut_rhs_sampled_batch",
+    "pa_cut_preprocess_agglomeration", "pa_cut_agglo_query", "pa_cut_query_tags", "pa_cut_quadrature_points", "pa_cut_rhs_sampled_batch",
     "pa_cut_interface_ops_batch", "pa_cut_interface_uncut_batch", "pa_interface_assembler_query",
     "pa_interface_triplets_batch", "pa_interface_cell_offsets",
 ]
@@ -142,6 +142,8 @@ def lib():
     L.pa_cut_local_ops_batch.argtypes = [vp, C.c_int, C.POINTER(LevelSet), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp]
     L.pa_cut_merge.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp]
     L.pa_cut_query_tags.argtypes = [vp, vp, vp, vp]
+    L.pa_cut_preprocess_agglomeration.argtypes = [vp, sz, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(LevelSet), C.c_int]
+    L.pa_cut_agglo_query.argtypes = [vp, vp, vp]
     L.pa_cut_quadrature_points.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(sz)]
     L.pa_cut_rhs_sampled_batch.argtypes = [vp, C.c_int, C.POINTER(LevelSet), C.c_int, dp, dp, dp]
     L.pa_cut_interface_ops_batch.argtypes = [vp, C.c_int, C.POINTER(LevelSet), C.POINTER(InterfaceParams), C.c_int, dp, dp, dp, dp, dp]
@@ -337,6 +339,18 @@ class Context:
 
     def cut_preprocess(self, Nx, Ny, ls, refsteps, lo=(0.0, 0.0), hi=(1.0, 1.0)):
         self._ck(self._L.pa_cut_preprocess(self.h, Nx, Ny, lo[0], hi[0], lo[1], hi[1], C.byref(ls), refsteps), "pa_cut_preprocess")
+
+    def cut_preprocess_agglomeration(self, Nx, Ny, ls, refsteps, lo=(0.0, 0.0), hi=(1.0, 1.0)):
+        self._ck(self._L.pa_cut_preprocess_agglomeration(self.h, Nx, Ny, lo[0], hi[0], lo[1], hi[1], C.byref(ls), refsteps),
+                 "pa_cut_preprocess_agglomeration")
+
+    def cut_agglo_query(self):
+        import numpy as np
+        nc = self.mesh_counts()[1]
+        agglo = np.zeros(nc, dtype=np.int8)
+        nb = np.zeros((nc, 8), dtype=np.int32)
+        self._ck(self._L.pa_cut_agglo_query(self.h, agglo.ctypes.data, nb.ctypes.data), "pa_cut_agglo_query")
+        return agglo, nb
 
     def cut_query(self):
         import numpy as np

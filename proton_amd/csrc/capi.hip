@@ -865,8 +865,40 @@ static int condense(pa_context *ctx, pa_degree_info di, size_t n, const double *
 }
 
 // ---- cutHHO -----------------------------------------------------------------------------------
+static int cut_preprocess_impl(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
+                               const pa_level_set *ls, int refsteps, bool displace);
+
 int pa_cut_preprocess(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
                       const pa_level_set *ls, int refsteps)
+{
+    return cut_preprocess_impl(ctx, Nx, Ny, min_x, max_x, min_y, max_y, ls, refsteps, true);
+}
+
+int pa_cut_preprocess_agglomeration(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
+                                    const pa_level_set *ls, int refsteps)
+{
+    return cut_preprocess_impl(ctx, Nx, Ny, min_x, max_x, min_y, max_y, ls, refsteps, false);
+}
+
+int pa_cut_agglo_query(pa_context *ctx, int8_t *agglo_set, int32_t *neighbors)
+{
+    if (!ctx) return PA_ERR_INVALID_ARG;
+    if (!ctx->cut) return PA_ERR_NO_MESH;
+    if (agglo_set) {
+        std::vector<int8_t> a;
+        pa::classify_agglomeration(*ctx->cut, a);
+        std::memcpy(agglo_set, a.data(), a.size());
+    }
+    if (neighbors) {
+        std::vector<int32_t> nb;
+        pa::structured_neighbors(ctx->cut->sm, nb);
+        std::memcpy(neighbors, nb.data(), nb.size() * sizeof(int32_t));
+    }
+    return PA_OK;
+}
+
+static int cut_preprocess_impl(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
+                               const pa_level_set *ls, int refsteps, bool displace)
 {
     if (!ctx || !ls || refsteps < 0 || refsteps > 10 || (ls->kind != 0 && ls->kind != 1)) return PA_ERR_INVALID_ARG;
     int st = pa_mesh_generate(ctx, Nx, Ny, min_x, max_x, min_y, max_y, 0, Ny);
@@ -875,7 +907,7 @@ int pa_cut_preprocess(pa_context *ctx, size_t Nx, size_t Ny, double min_x, doubl
     if (!cm) return PA_ERR_INVALID_ARG;
     const pa::LevelSet L = {ls->kind, ls->radius, ls->alpha, ls->beta, ls->cut_y};
     try {
-        pa::cut_preprocess(*cm, (uint32_t)Nx, (uint32_t)Ny, min_x, max_x, min_y, max_y, L, refsteps);
+        pa::cut_preprocess(*cm, (uint32_t)Nx, (uint32_t)Ny, min_x, max_x, min_y, max_y, L, refsteps, displace);
     } catch (const std::exception &e) {
         ctx->last_error = std::string("cutHHO preprocessing: ") + e.what();
         delete cm;

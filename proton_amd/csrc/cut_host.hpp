@@ -112,9 +112,11 @@ inline void tag_faces(CutMeshHost &m, const LevelSet &ls)                      /
     }
 }
 
-// Runs the default (-D) preprocessing; throws std::logic_error like the reference on bad cuts.
+// Runs the preprocessing of cuthho_square.cpp:2036-2052: with node displacement (-D, the default) or,
+// displace = false, the agglomeration branch (-A: no displacement; detect_cell_agglo_set is
+// classify_agglomeration below).  Throws std::logic_error like the reference on bad cuts.
 inline void cut_preprocess(CutMeshHost &m, uint32_t Nx, uint32_t Ny, double min_x, double max_x, double min_y, double max_y,
-                           const LevelSet &ls, int refsteps)
+                           const LevelSet &ls, int refsteps, bool displace = true)
 {
     m.sm = StructuredMesh{Nx, Ny, 0, Ny};
     const size_t np = m.npoints(), nc = m.ncells(), nf = m.nfaces();
@@ -128,7 +130,7 @@ inline void cut_preprocess(CutMeshHost &m, uint32_t Nx, uint32_t Ny, double min_
     m.node_loc.resize(np);                                                        // detect_node_position
     for (size_t n = 0; n < np; ++n) m.node_loc[n] = ls(m.pts[2 * n], m.pts[2 * n + 1]) < 0 ? LOC_NEG : LOC_POS;
     tag_faces(m, ls);
-    {                                                                             // move_nodes
+    if (displace) {                                                               // move_nodes
         std::vector<P2d> disp(np, P2d{0, 0});
         std::vector<uint8_t> moved(np, 0);
         for (uint32_t f = 0; f < nf; ++f) {
@@ -154,7 +156,7 @@ inline void cut_preprocess(CutMeshHost &m, uint32_t Nx, uint32_t Ny, double min_
             }
         }
     }
-    tag_faces(m, ls);                                                             // again: updated intersection points
+    if (displace) tag_faces(m, ls);                                               // again: updated intersection points
     m.cell_loc.assign(nc, LOC_UNDEF);                                             // detect_cut_cells
     m.cut_index.assign(nc, -1);
     m.cut_cells.clear();
@@ -205,6 +207,66 @@ inline void cut_preprocess(CutMeshHost &m, uint32_t Nx, uint32_t Ny, double min_
                 ifc[lo + span / 2] = ip;
             }
     }
+}
+
+// detect_cell_agglo_set (cuthho_geom.hpp:163-273): for every cut cell, how close the interface
+// passes to the cell's nodes along the two cut faces (threshold 0.3 of the face length).
+// 0 UNDEF (not cut), 1 T_OK, 2 T_KO_NEG, 3 T_KO_POS -- the reference's cell_agglo_set order.
+enum : int8_t { AGGLO_UNDEF = 0, AGGLO_T_OK = 1, AGGLO_T_KO_NEG = 2, AGGLO_T_KO_POS = 3 };
+
+inline void classify_agglomeration(const CutMeshHost &m, std::vector<int8_t> &agglo)
+{
+    const double threshold = 0.3;                                                 // :170
+    const size_t nc = m.ncells();
+    agglo.assign(nc, AGGLO_UNDEF);
+    for (uint32_t c = 0; c < nc; ++c) {
+        uint32_t fcs[4], ids[4];
+        m.cell_face_ids(c, fcs);
+        m.cell_ids(c, ids);
+        bool cut[4];
+        for (int i = 0; i < 4; ++i) cut[i] = m.face_loc[fcs[i]] == LOC_CUT;
+        auto rel_dist = [&](int node, int face) {                                 // |p_node - ip(face)| / |face|
+            uint32_t lo, hi;
+            m.face_ends(fcs[face], lo, hi);
+            return norm(m.point(ids[node]) - m.face_ip[fcs[face]]) / norm(m.point(hi) - m.point(lo));
+        };
+        for (int i = 0; i < 4; ++i) {                                             // two consecutive cut faces: one node cut off (:182-206, :243-252)
+            const int f1 = i, f2 = (i + 1) % 4, n = (i + 1) % 4;
+            if (!(cut[f1] && cut[f2])) continue;
+            const double da = rel_dist(n, f1), db = rel_dist(n, f2);             // faces n-1 and n of node n
+            if (std::min(da, db) > threshold) agglo[c] = AGGLO_T_OK;
+            else agglo[c] = m.node_loc[ids[n]] == LOC_NEG ? AGGLO_T_KO_NEG : AGGLO_T_KO_POS;
+        }
+        for (int f1 = 0; f1 < 2; ++f1) {                                          // two opposite cut faces (:208-241, :254-258)
+            const int f2 = f1 + 2;
+            if (!(cut[f1] && cut[f2])) continue;
+            const int n1 = f1, n2 = (f2 + 1) % 4;
+            const double da = rel_dist(n1, f1), db = rel_dist(n2, f2);
+            const double m1 = std::max(da, db), m2 = std::max(1 - da, 1 - db);
+            if (std::min(m1, m2) > threshold) { agglo[c] = AGGLO_T_OK; continue; }
+            if (m.node_loc[ids[n1]] == LOC_NEG) agglo[c] = (m1 <= threshold) ? AGGLO_T_KO_NEG : AGGLO_T_KO_POS;
+            else agglo[c] = (m2 <= threshold) ? AGGLO_T_KO_NEG : AGGLO_T_KO_POS;
+        }
+    }
+}
+
+// make_neighbors_info (cuthho_geom.hpp:343-370: cells sharing at least one point, found there by an
+// O(cells^2) search) in closed form on the generator mesh: the up-to-8 surrounding cells, ascending,
+// -1 padded.
+inline void structured_neighbors(const StructuredMesh &sm, std::vector<int32_t> &nb)
+{
+    nb.assign((size_t)sm.Nx * sm.Ny * 8, -1);
+    for (uint32_t j = 0; j < sm.Ny; ++j)
+        for (uint32_t i = 0; i < sm.Nx; ++i) {
+            int k = 0;
+            for (int dj = -1; dj <= 1; ++dj)
+                for (int di = -1; di <= 1; ++di) {
+                    if (!di && !dj) continue;
+                    const int64_t ii = (int64_t)i + di, jj = (int64_t)j + dj;
+                    if (ii < 0 || jj < 0 || ii >= sm.Nx || jj >= sm.Ny) continue;
+                    nb[((size_t)j * sm.Nx + i) * 8 + k++] = (int32_t)(jj * sm.Nx + ii);
+                }
+        }
 }
 
 // ---- quadrature lists ---------------------------------------------------------------------

@@ -151,6 +151,11 @@ def lib():
     L.cut_mesh_free.argtypes = [C.c_void_p]
     L.cut_mesh_free.restype = None
     L.cut_mesh_preprocess.argtypes = [C.c_void_p, lsp, C.c_int]
+    L.cut_mesh_preprocess_agglomeration.argtypes = [C.c_void_p, lsp, C.c_int]
+    L.cut_mesh_agglo_set.restype = None
+    L.cut_mesh_agglo_set.argtypes = [C.c_void_p, C.POINTER(C.c_int8)]
+    L.cut_mesh_neighbors.restype = None
+    L.cut_mesh_neighbors.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     for name in ("cut_mesh_num_points", "cut_mesh_num_cells", "cut_mesh_num_faces", "cut_mesh_interface_points"):
         getattr(L, name).restype = C.c_size_t
         getattr(L, name).argtypes = [C.c_void_p]
@@ -437,13 +442,13 @@ class ObstacleAssembler(Assembler):
 class CutMesh:
     """cuthho_poly_mesh + the preprocessing of cuthho_square.cpp:2036-2052 (oracle side)."""
 
-    def __init__(self, N, radius=0.35, center=(0.5, 0.5), refsteps=4):
+    def __init__(self, N, radius=0.35, center=(0.5, 0.5), refsteps=4, agglomeration=False):
         L = lib()
         self.L = L
         self.N = N
         self.ls = CutLevelSet(0, radius, center[0], center[1], 0.0)
         self.h = L.cut_mesh_create(N, N, 0.0, 1.0, 0.0, 1.0)
-        st = L.cut_mesh_preprocess(self.h, C.byref(self.ls), refsteps)
+        st = (L.cut_mesh_preprocess_agglomeration if agglomeration else L.cut_mesh_preprocess)(self.h, C.byref(self.ls), refsteps)
         if st != 0:
             raise RuntimeError("cut_mesh_preprocess failed: %d" % st)
         self.np_, self.nc, self.nf = (L.cut_mesh_num_points(self.h), L.cut_mesh_num_cells(self.h), L.cut_mesh_num_faces(self.h))
@@ -510,6 +515,16 @@ class CutMesh:
         st = self.L.cut_make_rhs(self.h, C.byref(self.ls), c, degree, where, self.L.hho_builtin_fn(f_id),
                                  self.L.hho_builtin_fn(bcs_id), None, _dp(out))
         return st, out
+
+    def agglo_set(self):
+        a = np.zeros(self.nc, dtype=np.int8)
+        self.L.cut_mesh_agglo_set(self.h, a.ctypes.data_as(C.POINTER(C.c_int8)))
+        return a
+
+    def neighbors(self):
+        nb = np.zeros((self.nc, 8), dtype=np.int32)
+        self.L.cut_mesh_neighbors(self.h, nb.ctypes.data_as(C.POINTER(C.c_int32)))
+        return nb
 
     # ---- two-sided interface problem (cuthho_square -i) ----
     def laplacian_interface(self, c, di, kappa_1=1.0, kappa_2=1.0, eta=5.0):

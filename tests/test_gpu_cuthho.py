@@ -217,3 +217,32 @@ def test_interface_end_to_end_matches_xlsx(asm, oracle, N, k):
 
     err, msh = cd.run_interface(N, k, 4, provider=gpu_provider)
     assert abs(err - REF[(k, N)]) / REF[(k, N)] < 6e-6
+
+
+@pytest.mark.parametrize("N", [10, 16, 33])
+def test_agglomeration_branch_matches_oracle(asm, oracle, N):
+    """pa_cut_preprocess_agglomeration + pa_cut_agglo_query (`-A`: no displacement, detect_cell_agglo_set,
+    make_neighbors_info) against the oracle: tags, classes and neighbour lists bit-exact; the cut operators
+    work on the undisplaced mesh too."""
+    from proton_amd.batch import to_rowcol
+    import proton_amd as pa
+    asm.level_set = pa.capi.LevelSet(0, 0.35, 0.5, 0.5, 0.0)
+    asm.ctx.cut_preprocess_agglomeration(N, N, asm.level_set, 4)
+    asm.ncut, asm.cell_loc, asm.cut_index = asm.ctx.cut_query()
+    ref = oracle.CutMesh(N, refsteps=4, agglomeration=True)
+    assert np.array_equal(asm.cell_loc, ref.cell_loc)
+    agglo, nb = asm.ctx.cut_agglo_query()
+    assert np.array_equal(agglo, ref.agglo_set())
+    if N <= 16:
+        assert np.array_equal(nb, ref.neighbors())
+    di = oracle.degrees(2, 1)
+    out = asm.cut_local_ops(1)
+    asm.synchronize()
+    lc = to_rowcol(out["lc"])
+    errs = []
+    for i, c in enumerate(np.nonzero(ref.cell_loc == oracle.CUT_ON_INTERFACE)[0]):
+        st, o_oper, o_data = ref.laplacian(int(c), di)
+        st, o_stab = ref.cut_stabilization(int(c), di)
+        errs.append(nerr(lc[i], o_data + o_stab))
+    # without node displacement the cuts can be arbitrarily bad (that is what the classes flag): cond * eps on both sides
+    assert np.median(errs) < 1e-11 and max(errs) < 1e-6, (np.median(errs), max(errs))

@@ -111,3 +111,50 @@ def test_cut_operator_shapes_and_symmetry(oracle):
     pos = int(np.nonzero(m.cell_loc == oracle.CUT_POS)[0][0])
     st, f = m.rhs(pos, di.cell_deg)
     assert st == 0 and np.all(f == 0.0)
+
+
+@pytest.mark.parametrize("N", [10, 16, 33])
+def test_agglomeration_branch_classification(oracle, N):
+    """`-A` (cuthho_square.cpp:2039-2044): no node displacement, detect_cell_agglo_set (cuthho_geom.hpp:163-273).
+    Every cut cell gets a class, uncut cells none; the classes inherit the symmetries of the circle on the
+    uniform mesh; single-node cuts are re-derived here from the face intersection points."""
+    m = oracle.CutMesh(N, agglomeration=True)
+    plain = oracle.make_mesh(N, N)[1]
+    assert np.array_equal(m.points, plain)                                   # nothing was displaced
+    a = m.agglo_set()
+    cut = m.cell_loc == oracle.CUT_ON_INTERFACE
+    assert np.all(a[cut] > 0) and np.all(a[~cut] == 0) and cut.sum() > 0
+    A = a.reshape(N, N)
+    assert np.array_equal(A, A[::-1, :]) and np.array_equal(A, A[:, ::-1]) and np.array_equal(A, A.T)
+    fip = np.ctypeslib.as_array(oracle.lib().cut_mesh_face_intersection(m.h), shape=(m.nf, 2))
+    checked = 0
+    for c in np.nonzero(cut)[0]:
+        fcs = [int(f) for f in m.cell_faces[c]]
+        cf = [m.face_loc[f] == oracle.CUT_ON_INTERFACE for f in fcs]
+        pts = m.points[m.ptids[c].astype(np.int64)]
+        for i in range(4):
+            f1, f2, n = i, (i + 1) % 4, (i + 1) % 4
+            if not (cf[f1] and cf[f2]):
+                continue
+            d = []
+            for f in (fcs[f1], fcs[f2]):
+                p0, p1 = m.points[int(m.faces[f, 0])], m.points[int(m.faces[f, 1])]
+                d.append(np.linalg.norm(pts[n] - fip[f]) / np.linalg.norm(p1 - p0))
+            node_neg = m.node_loc[int(m.ptids[c][n])] == oracle.CUT_NEG
+            want = 1 if min(d) > 0.3 else (2 if node_neg else 3)
+            assert a[c] == want
+            checked += 1
+    assert checked > 0
+
+
+def test_neighbors_literal_search_is_the_eight_neighbourhood(oracle):
+    """make_neighbors_info (cuthho_geom.hpp:343-370) restated literally (all pairs) == closed form"""
+    N = 7
+    m = oracle.CutMesh(N, agglomeration=True)
+    nb = m.neighbors()
+    for j in range(N):
+        for i in range(N):
+            want = sorted(jj * N + ii for jj in range(max(0, j - 1), min(N, j + 2)) for ii in range(max(0, i - 1), min(N, i + 2))
+                          if (ii, jj) != (i, j))
+            got = [int(v) for v in nb[j * N + i] if v >= 0]
+            assert got == want
