@@ -2,6 +2,7 @@
 // Thin: argument validation, kernel selection, launches on the context's stream.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -923,21 +924,32 @@ static int cut_preprocess_impl(pa_context *ctx, size_t Nx, size_t Ny, double min
     PA_HIP(ctx, hipMemcpyAsync(ctx->d_cut_cells, cm->cut_cells.data(), ncut * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     PA_HIP(ctx, hipMemcpyAsync(ctx->d_cell_loc, cm->cell_loc.data(), nc, hipMemcpyHostToDevice, ctx->stream));
     PA_HIP(ctx, hipMemcpyAsync(ctx->d_cut_index, cm->cut_index.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    // interface_assembler tables (cuthho_square.cpp:1142-1178): cut cells / cut faces own two blocks
+    // interface_assembler tables (cuthho_square.cpp:1142-1178): cut cells / cut faces own two blocks, so the
+    // first block of an element = its plain (compressed) index + the number of cut elements before it
     const size_t nf = cm->nfaces();
     std::vector<int32_t> cell_table(nc), face_table(nf);
-    size_t blocks = 0;
-    for (size_t c = 0; c < nc; ++c) { cell_table[c] = (int32_t)blocks; blocks += cm->cell_loc[c] == pa::LOC_CUT ? 2 : 1; }
-    ctx->if_num_all_cells = blocks;
-    blocks = 0;
-    for (uint32_t f = 0; f < nf; ++f) {
-        uint32_t lo, hi; bool dirichlet; int32_t comp;
-        pa::sm_face_decode(cm->sm, f, lo, hi, dirichlet, comp);
-        if (dirichlet) { face_table[f] = -1; continue; }
-        face_table[f] = (int32_t)blocks;
-        blocks += cm->face_loc[f] == pa::LOC_CUT ? 2 : 1;
+    std::vector<uint32_t> cut_faces;
+    for (uint32_t cc : cm->cut_cells) {                     // every cut face belongs to a cut cell
+        uint32_t fcs[4];
+        cm->cell_face_ids(cc, fcs);
+        for (int i = 0; i < 4; ++i)
+            if (cm->face_loc[fcs[i]] == pa::LOC_CUT) cut_faces.push_back(fcs[i]);
     }
-    ctx->if_num_other_faces = blocks;
+    std::sort(cut_faces.begin(), cut_faces.end());
+    cut_faces.erase(std::unique(cut_faces.begin(), cut_faces.end()), cut_faces.end());
+    pa::parallel_ranges(nc, [&](size_t c0, size_t c1) {
+        for (size_t c = c0; c < c1; ++c)
+            cell_table[c] = (int32_t)(c + (std::lower_bound(cm->cut_cells.begin(), cm->cut_cells.end(), (uint32_t)c) - cm->cut_cells.begin()));
+    });
+    ctx->if_num_all_cells = nc + ncut;
+    pa::parallel_ranges(nf, [&](size_t f0, size_t f1) {
+        for (uint32_t f = (uint32_t)f0; f < f1; ++f) {
+            uint32_t lo, hi; bool dirichlet; int32_t comp;
+            pa::sm_face_decode(cm->sm, f, lo, hi, dirichlet, comp);
+            face_table[f] = dirichlet ? -1 : comp + (int32_t)(std::lower_bound(cut_faces.begin(), cut_faces.end(), f) - cut_faces.begin());
+        }
+    });
+    ctx->if_num_other_faces = pa::sm_num_other_faces(cm->sm) + cut_faces.size();      // cut faces are never on the boundary
     PA_HIP(ctx, hipMalloc((void **)&ctx->d_face_loc, nf));
     PA_HIP(ctx, hipMalloc((void **)&ctx->d_if_cell_table, nc * sizeof(int32_t)));
     PA_HIP(ctx, hipMalloc((void **)&ctx->d_if_face_table, nf * sizeof(int32_t)));

@@ -12,9 +12,12 @@
 // Its own data model (struct-of-arrays over the generator mesh), not the reference's classes.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <exception>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "hho_assembly.hpp"      // StructuredMesh closed forms
@@ -38,6 +41,26 @@ struct LevelSet {
         nx = gx / nrm; ny = gy / nrm;
     }
 };
+
+// The O(cells) sweeps of the preprocessing (level-set evaluation at every node, tags of every face
+// and cell) are independent per element: contiguous index ranges on the host's hardware threads.
+// Every element sees the same arithmetic as in a serial sweep, so the results are bit-identical.
+template <typename Fn>
+inline void parallel_ranges(size_t n, Fn fn)
+{
+    const size_t hw = std::max<size_t>(1, std::min<size_t>(16, std::thread::hardware_concurrency()));
+    const size_t nt = n < 65536 ? 1 : hw;
+    if (nt == 1) { fn((size_t)0, n); return; }
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> errs(nt);
+    for (size_t t = 0; t < nt; ++t)
+        pool.emplace_back([&, t]() {
+            try { fn(n * t / nt, n * (t + 1) / nt); } catch (...) { errs[t] = std::current_exception(); }
+        });
+    for (auto &th : pool) th.join();
+    for (auto &e : errs)
+        if (e) std::rethrow_exception(e);
+}
 
 struct P2d { double x, y; };
 inline P2d operator+(P2d a, P2d b) { return {a.x + b.x, a.y + b.y}; }
@@ -100,16 +123,18 @@ inline void tag_faces(CutMeshHost &m, const LevelSet &ls)                      /
     const size_t nf = m.nfaces();
     m.face_loc.assign(nf, LOC_UNDEF);
     m.face_ip.assign(nf, P2d{0, 0});
-    for (uint32_t f = 0; f < nf; ++f) {
-        uint32_t lo, hi;
-        m.face_ends(f, lo, hi);
-        const P2d p0 = m.point(lo), p1 = m.point(hi);
-        const double l0 = ls(p0.x, p0.y), l1 = ls(p1.x, p1.y);
-        if (l0 >= 0 && l1 >= 0) { m.face_loc[f] = LOC_POS; continue; }
-        if (l0 < 0 && l1 < 0) { m.face_loc[f] = LOC_NEG; continue; }
-        m.face_ip[f] = zero_crossing(p0, p1, ls, norm(p1 - p0) / 1e4);
-        m.face_loc[f] = LOC_CUT;
-    }
+    parallel_ranges(nf, [&](size_t f0, size_t f1) {
+        for (uint32_t f = (uint32_t)f0; f < f1; ++f) {
+            uint32_t lo, hi;
+            m.face_ends(f, lo, hi);
+            const P2d p0 = m.point(lo), p1 = m.point(hi);
+            const double l0 = ls(p0.x, p0.y), l1 = ls(p1.x, p1.y);
+            if (l0 >= 0 && l1 >= 0) { m.face_loc[f] = LOC_POS; continue; }
+            if (l0 < 0 && l1 < 0) { m.face_loc[f] = LOC_NEG; continue; }
+            m.face_ip[f] = zero_crossing(p0, p1, ls, norm(p1 - p0) / 1e4);
+            m.face_loc[f] = LOC_CUT;
+        }
+    });
 }
 
 // Runs the preprocessing of cuthho_square.cpp:2036-2052: with node displacement (-D, the default) or,
@@ -122,13 +147,15 @@ inline void cut_preprocess(CutMeshHost &m, uint32_t Nx, uint32_t Ny, double min_
     const size_t np = m.npoints(), nc = m.ncells(), nf = m.nfaces();
     const double hx = (max_x - min_x) / Nx, hy = (max_y - min_y) / Ny;
     m.pts.resize(2 * np);
-    for (size_t j = 0; j <= Ny; ++j)
-        for (size_t i = 0; i <= Nx; ++i) {
-            m.pts[2 * (j * (Nx + 1) + i)] = min_x + i * hx;
-            m.pts[2 * (j * (Nx + 1) + i) + 1] = min_y + j * hy;
+    m.node_loc.resize(np);
+    parallel_ranges(np, [&](size_t n0, size_t n1) {
+        for (size_t n = n0; n < n1; ++n) {
+            const size_t i = n % (Nx + 1), j = n / (Nx + 1);
+            m.pts[2 * n] = min_x + i * hx;
+            m.pts[2 * n + 1] = min_y + j * hy;
+            m.node_loc[n] = ls(m.pts[2 * n], m.pts[2 * n + 1]) < 0 ? LOC_NEG : LOC_POS;      // detect_node_position
         }
-    m.node_loc.resize(np);                                                        // detect_node_position
-    for (size_t n = 0; n < np; ++n) m.node_loc[n] = ls(m.pts[2 * n], m.pts[2 * n + 1]) < 0 ? LOC_NEG : LOC_POS;
+    });
     tag_faces(m, ls);
     if (displace) {                                                               // move_nodes
         std::vector<P2d> disp(np, P2d{0, 0});
@@ -146,42 +173,52 @@ inline void cut_preprocess(CutMeshHost &m, uint32_t Nx, uint32_t Ny, double min_
         }
         for (size_t n = 0; n < np; ++n)
             if (moved[n]) { m.pts[2 * n] += disp[n].x; m.pts[2 * n + 1] += disp[n].y; }
-        for (uint32_t c = 0; c < nc; ++c) {
-            uint32_t ids[4];
-            m.cell_ids(c, ids);
-            if (!(moved[ids[0]] | moved[ids[1]] | moved[ids[2]] | moved[ids[3]])) continue;
-            for (int i = 0; i < 4; ++i) {
-                const P2d v1 = m.point(ids[(i + 1) % 4]) - m.point(ids[i]), v2 = m.point(ids[(i + 2) % 4]) - m.point(ids[(i + 1) % 4]);
-                if (v1.x * v2.y - v2.x * v1.y < 0) throw std::logic_error("concave poly");
+        parallel_ranges(nc, [&](size_t c0, size_t c1) {
+            for (uint32_t c = (uint32_t)c0; c < c1; ++c) {
+                uint32_t ids[4];
+                m.cell_ids(c, ids);
+                if (!(moved[ids[0]] | moved[ids[1]] | moved[ids[2]] | moved[ids[3]])) continue;
+                for (int i = 0; i < 4; ++i) {
+                    const P2d v1 = m.point(ids[(i + 1) % 4]) - m.point(ids[i]), v2 = m.point(ids[(i + 2) % 4]) - m.point(ids[(i + 1) % 4]);
+                    if (v1.x * v2.y - v2.x * v1.y < 0) throw std::logic_error("concave poly");
+                }
             }
-        }
+        });
     }
     if (displace) tag_faces(m, ls);                                               // again: updated intersection points
     m.cell_loc.assign(nc, LOC_UNDEF);                                             // detect_cut_cells
     m.cut_index.assign(nc, -1);
     m.cut_cells.clear();
+    parallel_ranges(nc, [&](size_t c0, size_t c1) {                               // tags: independent per cell
+        for (uint32_t c = (uint32_t)c0; c < c1; ++c) {
+            uint32_t fcs[4], ids[4];
+            m.cell_face_ids(c, fcs);
+            m.cell_ids(c, ids);
+            int k = 0;
+            for (int i = 0; i < 4; ++i) k += m.face_loc[fcs[i]] == LOC_CUT;
+            if (k == 0) {
+                bool all_pos = true;
+                for (int v = 0; v < 4; ++v) { const P2d p = m.point(ids[v]); all_pos = all_pos && ls(p.x, p.y) > 0; }
+                m.cell_loc[c] = all_pos ? LOC_POS : LOC_NEG;
+            } else if (k == 2) m.cell_loc[c] = LOC_CUT;
+            else throw std::logic_error("invalid number of cuts in cell");
+        }
+    });
     std::vector<P2d> p0p1;
-    for (uint32_t c = 0; c < nc; ++c) {
-        uint32_t fcs[4], ids[4];
+    for (uint32_t c = 0; c < nc; ++c) {                                           // cut cells in ascending order, interface endpoints
+        if (m.cell_loc[c] != LOC_CUT) continue;
+        uint32_t fcs[4];
         m.cell_face_ids(c, fcs);
-        m.cell_ids(c, ids);
         int k = 0;
         P2d cut[2] = {{0, 0}, {0, 0}};
         for (int i = 0; i < 4; ++i)
-            if (m.face_loc[fcs[i]] == LOC_CUT) { if (k < 2) cut[k] = m.face_ip[fcs[i]]; ++k; }
-        if (k == 0) {
-            bool all_pos = true;
-            for (int v = 0; v < 4; ++v) { const P2d p = m.point(ids[v]); all_pos = all_pos && ls(p.x, p.y) > 0; }
-            m.cell_loc[c] = all_pos ? LOC_POS : LOC_NEG;
-        } else if (k == 2) {
-            m.cell_loc[c] = LOC_CUT;
-            const P2d pt = cut[1] - cut[0], pn = cut[0] + P2d{-pt.y, pt.x};
-            const bool swap = ls(pn.x, pn.y) >= 0;
-            m.cut_index[c] = (int32_t)m.cut_cells.size();
-            m.cut_cells.push_back(c);
-            p0p1.push_back(swap ? cut[1] : cut[0]);
-            p0p1.push_back(swap ? cut[0] : cut[1]);
-        } else throw std::logic_error("invalid number of cuts in cell");
+            if (m.face_loc[fcs[i]] == LOC_CUT) cut[k++] = m.face_ip[fcs[i]];
+        const P2d pt = cut[1] - cut[0], pn = cut[0] + P2d{-pt.y, pt.x};
+        const bool swap = ls(pn.x, pn.y) >= 0;
+        m.cut_index[c] = (int32_t)m.cut_cells.size();
+        m.cut_cells.push_back(c);
+        p0p1.push_back(swap ? cut[1] : cut[0]);
+        p0p1.push_back(swap ? cut[0] : cut[1]);
     }
     // refine_interface: 2^refsteps segments per cut cell, midpoints pushed onto the interface by bisection
     const size_t nseg = (size_t)1 << refsteps;
