@@ -235,6 +235,25 @@ __device__ __forceinline__ double lds_dotadd(double s, const double *p, const do
     return s;
 }
 
+// value of lane j of every G-lane group, broadcast to the lanes of that group.  j is a constant after
+// unrolling: v_readlane_b32 (scalar result, no LDS round trip like ds_bpermute) + a select per group.
+template <int G>
+__device__ __forceinline__ double group_broadcast(double v, int j)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int rlo = __builtin_amdgcn_readlane(lo, j), rhi = __builtin_amdgcn_readlane(hi, j);
+    if (G < 64) {
+        const int grp = (int)(threadIdx.x & 63) / G;
+#pragma unroll
+        for (int g = 1; g < 64 / G; ++g) {
+            const int slo = __builtin_amdgcn_readlane(lo, g * G + j), shi = __builtin_amdgcn_readlane(hi, g * G + j);
+            rlo = grp == g ? slo : rlo;
+            rhi = grp == g ? shi : rhi;
+        }
+    }
+    return __hiloint2double(rhi, rlo);
+}
+
 // -------------------------------------------------------------------------------------
 // Cholesky of an N x N SPD matrix in LDS, one lane per row.  The matrix is symmetric and is
 // overwritten ROW-major: L[i][k] lands at A[i * LD + k] (rows contiguous and 16-byte aligned,
@@ -258,7 +277,7 @@ __device__ __forceinline__ int lds_cholesky(double *A, int l)
     for (int j = 0; j < N; ++j) {
         // A[i][j] - sum_{k<j} L[i][k] L[j][k]; row j's prefix is already in LDS
         const double s = j == 0 ? row[0] : lds_dotsub_n(row[j], A + j * LD, row, j);
-        const double d = __shfl(s, j, G);
+        const double d = group_broadcast<G>(s, j);
         if (!(d > 0.0) && !bad) bad = j + 1;
         const double r = fast_rsqrt<RSQ_ITERS>(d);   // seed 2^-26 -> ~3e-16 after one Newton step
         row[j] = s * r;
