@@ -164,6 +164,7 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="cell rows timed by the CPU baseline (0 = auto, ~15 s)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this pool
     import torch
     import torch.distributed as dist
     import proton_amd as pa
@@ -190,6 +191,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.barrier()                                     # communicators exist before anything is timed
 
     w = WORKLOADS[args.workload]
     N = w["N"]
