@@ -17,8 +17,20 @@ OBJ_DIR = os.path.join(HERE, "lib", "obj")
 LIB_PATH = os.path.join(HERE, "lib", "libproton_amd.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+if os.environ.get("PA_EXTRA_FLAGS"):        # experiments: extra compiler flags, e.g. "-mllvm -amdgpu-use-amdgpu-trackers"
+    FLAGS.extend(os.environ["PA_EXTRA_FLAGS"].split())
 if os.environ.get("PA_WAVES_PER_EU"):      # tuning knob: register budget of the local-operator kernel
     FLAGS.append("-DPA_WAVES_PER_EU=" + os.environ["PA_WAVES_PER_EU"])
+
+
+# Per-instance compiler settings, each measured on the MI355X against the default:
+# the AMDGPU register-pressure trackers cut the spills of these three instances (k = 2 tensor: 56 -> 26
+# spilled VGPRs at 4 waves/SIMD, which then beats 3 waves by 2 %); they hurt the (0,1) and (4,3) ones.
+PER_CONFIG_FLAGS = {
+    (3, 2, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_WAVES_PER_EU=4"],
+    (3, 2, 1): ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
+    (2, 1, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
+}
 
 
 def hipcc():
@@ -62,7 +74,9 @@ def build(force=False, verbose=False, jobs=None):
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
             todo.append((os.path.join(CSRC, "hho_inst.hip"), obj,
-                         ["-DPA_CD=%d" % cd, "-DPA_FD=%d" % fd, "-DPA_QUAD=%d" % q, "-DPA_GMIN=%d" % gmin]))
+                         ["-DPA_CD=%d" % cd, "-DPA_FD=%d" % fd, "-DPA_QUAD=%d" % q, "-DPA_GMIN=%d" % gmin] +
+                         ([] if os.environ.get("PA_WAVES_PER_EU") or os.environ.get("PA_EXTRA_FLAGS")
+                          else PER_CONFIG_FLAGS.get((cd, fd, q), []))))
     for unit in ("capi", "csr", "solver"):
         unit_obj = os.path.join(OBJ_DIR, unit + ".o")
         objs.append(unit_obj)
