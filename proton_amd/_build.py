@@ -29,7 +29,7 @@ if os.environ.get("PA_WAVES_PER_EU"):      # tuning knob: register budget of the
 PER_CONFIG_FLAGS = {
     (3, 2, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_WAVES_PER_EU=4"],
     (3, 2, 1): ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
-    (2, 1, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
+    (2, 1, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_WAVES_PER_EU=4"],
 }
 
 

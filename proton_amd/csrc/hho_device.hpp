@@ -95,7 +95,8 @@ struct Cfg {
     static constexpr int CPW = 64 / G;                        // cells per wavefront
     static constexpr int PPL = cdiv(NP, G);                   // evaluation points per lane
     static constexpr int MPL = cdiv(NMOM, G);                 // moments per lane
-    static constexpr int SPL = cdiv(RBS * RBS, G);            // stiffness entries per lane
+    static constexpr int NSYM = RBS * (RBS + 1) / 2;          // stiffness is symmetric: packed lower triangle
+    static constexpr int SPL = cdiv(NSYM, G);                 // stiffness entries per lane
     static constexpr int ND = MS / 2 + 1;                     // rotations of the symmetric update
     // register budget: the k = 3 kernels need > 168 VGPRs to run without spills (measured: 2 waves/SIMD
     // without spills beat 3 with), the others fit 3 waves/SIMD
@@ -513,21 +514,26 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
     }
     // stiffness entries owned by this lane: stiff(i,j) = ih^2 (a a' MOM(a+a'-2, b+b') + b b' MOM(a+a', b+b'-2))
     // packed as idx1 | idx2<<8 | c1<<16 | c2<<24   (bases.hpp:170-176 with hho.hpp:57-61)
-    uint32_t st_code[C::SPL];
+    // (i, j <= i of the packed lower triangle; the mirror entry is written with it) in bits 0-7 / 8-15 of st_ij
+    uint32_t st_code[C::SPL], st_ij[C::SPL];
 #pragma unroll
     for (int t = 0; t < C::SPL; ++t) {
         const int e = l + t * G;
-        uint32_t code = 0;
-        if (e < RBS * RBS) {
+        uint32_t code = 0, ij = 0;
+        if (e < C::NSYM) {
+            int i = 0;
+            while ((i + 1) * (i + 2) / 2 <= e) ++i;
+            const int j = e - i * (i + 1) / 2;
             int ai, bi, aj, bj;
-            mono_exps(e % RBS, ai, bi);
-            mono_exps(e / RBS, aj, bj);
+            mono_exps(i, ai, bi);
+            mono_exps(j, aj, bj);
             const int c1 = ai * aj, c2 = bi * bj;
             const int i1 = c1 ? mono_index(ai + aj - 2, bi + bj) : 0;
             const int i2 = c2 ? mono_index(ai + aj, bi + bj - 2) : 0;
             code = (uint32_t)i1 | ((uint32_t)i2 << 8) | ((uint32_t)c1 << 16) | ((uint32_t)c2 << 24);
+            ij = (uint32_t)i | ((uint32_t)j << 8);
         }
-        st_code[t] = code;
+        st_code[t] = code; st_ij[t] = ij;
     }
     // column role of this lane: cell column (c < CBS) or column kf of face fc
     const bool is_col = l < MS, is_cellcol = l < CBS;
@@ -699,11 +705,16 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
 #pragma unroll
             for (int t = 0; t < C::SPL; ++t) {
                 const int e = l + t * G;
-                if (e < RBS * RBS) {
-                    const uint32_t code = st_code[t];
+                if (e < C::NSYM) {
+                    // decoded here, per cell: hoisted, the decoded offsets and coefficients would cost
+                    // six registers per entry for the whole kernel
+                    uint32_t code = st_code[t], ij = st_ij[t];
+                    asm volatile("" : "+v"(code), "+v"(ij));
                     const double c1 = (double)((code >> 16) & 0xff), c2 = (double)(code >> 24);
-                    const double v = c1 * S[C::oMOM + (code & 0xff)] + c2 * S[C::oMOM + ((code >> 8) & 0xff)];
-                    S[C::oST + (e % RBS) + (e / RBS) * LD] = ih2 * v;
+                    const double v = ih2 * (c1 * S[C::oMOM + (code & 0xff)] + c2 * S[C::oMOM + ((code >> 8) & 0xff)]);
+                    const int i = (int)(ij & 0xff), j = (int)(ij >> 8);
+                    S[C::oST + i + j * LD] = v;
+                    S[C::oST + j + i * LD] = v;
                 }
             }
             if (C::GENERAL_FANCY) {

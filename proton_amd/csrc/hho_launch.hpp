@@ -14,6 +14,7 @@ struct KernelEntry {
     const void *func;          // for the occupancy query
     int lds_bytes;
     const char *name;
+    int waves_per_simd;        // the occupancy the instance is tuned for (Cfg::WAVES): the grid does not exceed it
 };
 
 template <class C, bool SPLIT>
