@@ -278,10 +278,30 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kern_ms = sum(a.elapsed_time(b) for sa, sb in zip(k_start, k_stop) for a, b in zip(sa, sb)) / args.steps
-    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cpu" if rehearsal else dev)
+
+    # N > 1, informational (not `value`): the same K steps without the exchange -- local operators, right-hand
+    # sides and condensation of every rank's cells, no collective -- so that the cost of the all_gather is visible
+    elapsed_noex = None
+    if exchange:
+        def step_noex():
+            asm.ctx.local_ops(di, quad, stab, 0, n_local, None, None, None, lc.data_ptr(), None)
+            asm.ctx.cell_rhs(w["cd"], w["dinc"], quad, w["fn"], 0, n_local, rhs.data_ptr(), None)
+            for k in range(ex.chunks):
+                first, n = ex.piece_cells(k)
+                S_view, g_view = ex.local_S_g(k, nf)
+                asm.ctx.static_condensation_packed(di, n, lc[first:first + n].data_ptr(), rhs[first:first + n].data_ptr(),
+                                                   S_view.data_ptr(), g_view.data_ptr(), None)
+        step_noex()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_noex()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        elapsed_noex = time.perf_counter() - t1
+    t = torch.tensor([elapsed, kern_ms, elapsed_noex or 0.0], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms = float(t[0]), float(t[1])
+    elapsed, kern_ms, elapsed_noex = float(t[0]), float(t[1]), float(t[2])
 
     # sanity: the timed work produced finite local matrices (not a cached / skipped result)
     probe = lc[:: max(1, n_local // 64)]
@@ -338,6 +358,9 @@ def main():
                 "frac": n_local * fl / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                 "reference_flops_per_cell": fl, "source": "SURVEY.md 8(d) operation-count model of the reference's algorithm, +-30 %"})(
                     REFERENCE_FLOPS_PER_CELL.get((w["cd"], w["fd"], w["quad"], w["stab"]))),
+            "without_exchange": None if not exchange else {
+                "value": total_cells / (elapsed_noex / args.steps), "unit": "cells/s", "ms_per_step": elapsed_noex / args.steps * 1e3,
+                "what": "the same steps (local operators + rhs + condensation on every rank) without the all_gather, max over ranks"},
             "kernel_only_cells_per_s": total_cells / (kern_ms * 1e-3) if world == 1 else n_local * world / (kern_ms * 1e-3),
         }
         if not args.no_cpu_baseline and world == 1:

@@ -853,11 +853,12 @@ static int condense(pa_context *ctx, pa_degree_info di, size_t n, const double *
     const int st = pa_sizes_for(di, PA_QUAD_TENSOR, &sz);
     if (st != PA_OK && st != PA_ERR_QUADRATURE) return st;
     if (n == 0) return PA_OK;
-    const size_t resident = (size_t)ctx->num_cus * 16;
-    const int grid = (int)(n < resident ? n : resident);
 #define PA_SC_CASE(CD, FD)                                                                                    \
     if (di.cell_deg == CD && di.face_deg == FD) {                                                             \
-        hipLaunchKernelGGL((pa::static_condensation_kernel<pa::P2(CD), 4 * (FD + 1)>), dim3(grid), dim3(64), 0, \
+        constexpr int G_ = (pa::P2(CD) <= 16 && 4 * (FD + 1) + 1 <= 16) ? 16 : 32;                            \
+        const size_t blocks = (n + 64 / G_ - 1) / (64 / G_), resident = (size_t)ctx->num_cus * 16;             \
+        const int grid = (int)(blocks < resident ? blocks : resident);                                        \
+        hipLaunchKernelGGL((pa::static_condensation_kernel<pa::P2(CD), 4 * (FD + 1), G_>), dim3(grid), dim3(64), 0, \
                            ctx->stream, n, d_lc, d_rhs, d_S, d_g, d_rec, d_info, packed);                     \
         PA_HIP(ctx, hipGetLastError());                                                                       \
         return PA_OK;                                                                                         \

@@ -259,58 +259,91 @@ __global__ __launch_bounds__(256) void cell_project_kernel(const QuadTables *tab
     if (info != nullptr) info[t] = bad;
 }
 
-// Static condensation, one wavefront per cell (not on the reference's path; used by the
-// face-DOF triplet path of the multi-GPU exchange).  A = lc (MS x MS), T = first CBS dofs.
+// Static condensation (not on the reference's path; the face-dof form of the multi-GPU exchange).
+// A = lc (MS x MS), T = first CBS dofs:
 //   rec = A_TT^-1 [ f_T | -A_TF ],  S = A_FF + A_FT rec[:,1:],  g = -A_FT rec[:,0]
-template <int CBS, int NF>
+// G lanes per cell (16 for k <= 2, 32 for k = 3), 64 / G cells per wavefront, persistent grid.  The
+// cell's matrix is staged in LDS with coalesced 16-byte loads (reading the needed blocks straight from
+// HBM, strided, was measured 40 % slower).  Lane c owns column c of rec (c = 0: the right-hand side,
+// c >= 1: face dof c-1) in registers from the substitutions to the Schur column; A_FT is read from
+// LDS as broadcast rows.
+template <int CBS, int NF, int G>
 __global__ __launch_bounds__(64) void static_condensation_kernel(size_t n, const double *lc, const double *rhs,
                                                                  double *Sout, double *gout, double *recout,
                                                                  int32_t *info, int packed)
 {
-    constexpr int MS = CBS + NF, G = 64;
-    static_assert(NF + 1 <= G && CBS <= G, "one lane per column");
-    __shared__ double A[MS * MS];
-    __shared__ double LT[CBS * CBS];
-    __shared__ double REC[CBS * (NF + 1)];
-    const int l = threadIdx.x;
-    for (size_t cell = blockIdx.x; cell < n; cell += gridDim.x) {
+    constexpr int MS = CBS + NF, CPW = 64 / G, LDC = (CBS + 1) & ~1;
+    constexpr int oA = 0, oLT = (MS * MS + 1) & ~1, PER_CELL = (oLT + CBS * LDC + 1) & ~1;
+    static_assert(NF + 1 <= G && CBS <= G, "one lane per column / per row");
+    __shared__ __attribute__((aligned(16))) double smem[CPW * PER_CELL];
+    const int lane = threadIdx.x, g = lane / G, l = lane % G;
+    double *A = smem + g * PER_CELL + oA, *LT = smem + g * PER_CELL + oLT;
+    const size_t stride = (size_t)gridDim.x * CPW;
+    for (size_t base = (size_t)blockIdx.x * CPW; base < n; base += stride) {
+        const bool valid = base + g < n;
+        const size_t cell = valid ? base + g : n - 1;
         const double *src = lc + cell * (size_t)(MS * MS);
-        for (int e = l; e < MS * MS; e += G) A[e] = src[e];
-        __syncthreads();
-        for (int e = l; e < CBS * CBS; e += G) LT[e] = A[(e % CBS) + (e / CBS) * MS];
-        __syncthreads();
-        const int bad = lds_cholesky<CBS, CBS, G>(LT, l);
-        {
-            double x[CBS];
-            const int c = l <= NF ? l : 0;
-#pragma unroll
-            for (int i = 0; i < CBS; ++i)
-                x[i] = (c == 0) ? (rhs != nullptr ? rhs[cell * CBS + i] : 0.0) : -A[i + (CBS + c - 1) * MS];
-            lds_forward<CBS, CBS>(LT, x);
-            lds_backward<CBS, CBS>(LT, x);
-            if (l <= NF) {
-#pragma unroll
-                for (int i = 0; i < CBS; ++i) REC[i + c * CBS] = x[i];
-            }
+        if ((MS * MS) % 2 == 0) {                          // every cell block is 16-byte aligned
+            for (int e = l; e < MS * MS / 2; e += G)
+                *reinterpret_cast<double2 *>(A + 2 * e) = *reinterpret_cast<const double2 *>(src + 2 * e);
+        } else {
+            for (int e = l; e < MS * MS; e += G) A[e] = src[e];
         }
         __syncthreads();
-        if (Sout != nullptr)
-            for (int e = l; e < NF * NF; e += G) {
-                const int i = e % NF, j = e / NF;
-                if (packed && i > j) continue;                     // S is symmetric: upper triangle, column-packed
-                double s = A[(CBS + i) + (CBS + j) * MS];
-                for (int k = 0; k < CBS; ++k) s += A[(CBS + i) + k * MS] * REC[k + (1 + j) * CBS];
-                if (packed) Sout[cell * (size_t)(NF * (NF + 1) / 2) + j * (j + 1) / 2 + i] = s;
-                else Sout[cell * (size_t)(NF * NF) + e] = s;
-            }
-        if (gout != nullptr && l < NF) {
-            double s = 0.0;
-            for (int k = 0; k < CBS; ++k) s -= A[(CBS + l) + k * MS] * REC[k];
-            gout[cell * NF + l] = s;
+        for (int e = l; e < CBS * CBS; e += G) LT[(e / CBS) * LDC + (e % CBS)] = A[(e % CBS) + (e / CBS) * MS];     // A_TT (symmetric)
+        __syncthreads();
+        const int bad = lds_cholesky<CBS, LDC, G>(LT, l);
+        double x[CBS];
+        const int c = l <= NF ? l : 0;
+#pragma unroll
+        for (int i = 0; i < CBS; ++i)
+            x[i] = (c == 0) ? (rhs != nullptr ? rhs[cell * CBS + i] : 0.0) : -A[i + (CBS + c - 1) * MS];
+        lds_forward<CBS, LDC>(LT, x);
+        lds_backward<CBS, LDC>(LT, x);
+        if (recout != nullptr && valid && l <= NF) {
+#pragma unroll
+            for (int i = 0; i < CBS; ++i) recout[cell * (size_t)(CBS * (NF + 1)) + (size_t)c * CBS + i] = x[i];
         }
-        if (recout != nullptr)
-            for (int e = l; e < CBS * (NF + 1); e += G) recout[cell * (size_t)(CBS * (NF + 1)) + e] = REC[e];
-        if (info != nullptr && l == 0) info[cell] = bad;
+        double v[NF];                                       // v = A_FT x : rows CBS.. of column k of A are contiguous
+#pragma unroll
+        for (int i = 0; i < NF; ++i) v[i] = 0.0;
+#pragma unroll
+        for (int k = 0; k < CBS; ++k) {
+            const double *col = A + CBS + k * MS;
+            if (CBS % 2 == 0 && MS % 2 == 0) {              // 16-byte aligned runs: ds_read_b128
+#pragma unroll
+                for (int i = 0; i < NF; i += 2) {
+                    const double2 p = lds_pair(col + i);
+                    v[i] = __builtin_fma(p.x, x[k], v[i]);
+                    v[i + 1] = __builtin_fma(p.y, x[k], v[i + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NF; ++i) v[i] = __builtin_fma(col[i], x[k], v[i]);
+            }
+        }
+        if (valid && l <= NF) {
+            if (c == 0) {
+                if (gout != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) gout[cell * NF + i] = -v[i];
+                }
+            } else if (Sout != nullptr) {
+                const int j = c - 1;
+                const double *aff = A + CBS + (CBS + j) * MS;                    // A_FF(:, j)
+                if (packed) {
+                    double *dst = Sout + cell * (size_t)(NF * (NF + 1) / 2) + j * (j + 1) / 2;      // rows 0..j of column j
+#pragma unroll
+                    for (int i = 0; i < NF; ++i)
+                        if (i <= j) dst[i] = aff[i] + v[i];
+                } else {
+                    double *dst = Sout + cell * (size_t)(NF * NF) + (size_t)j * NF;
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) dst[i] = aff[i] + v[i];
+                }
+            }
+        }
+        if (info != nullptr && valid && l == 0) info[cell] = bad;
         __syncthreads();
     }
 }
