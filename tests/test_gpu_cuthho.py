@@ -246,3 +246,30 @@ def test_agglomeration_branch_matches_oracle(asm, oracle, N):
         errs.append(nerr(lc[i], o_data + o_stab))
     # without node displacement the cuts can be arbitrarily bad (that is what the classes flag): cond * eps on both sides
     assert np.median(errs) < 1e-11 and max(errs) < 1e-6, (np.median(errs), max(errs))
+
+
+def test_interface_assembler_without_cut_cells_is_the_plain_assembler(asm):
+    """A level set that cuts nothing (circle outside the unit square): no duplicated unknowns, and
+    interface_assembler's triplets are assembler's (hho.hpp:344-406) slot for slot; the cut batches are empty."""
+    import ctypes as C
+    import torch
+    import proton_amd as pa
+    N, k = 9, 1
+    asm.level_set = pa.capi.LevelSet(0, 2.0, 0.5, 0.5, 0.0)
+    asm.ctx.cut_preprocess(N, N, asm.level_set, 4)
+    asm.ncut, asm.cell_loc, asm.cut_index = asm.ctx.cut_query()
+    assert asm.ncut == 0 and np.all(asm.cell_loc == 0)
+    info = asm.ctx.interface_info(k)
+    plain = asm.assembler_info(k + 1, k)
+    assert (info.num_all_cells, info.num_other_faces, info.system_size) == (N * N, plain.num_other_faces, plain.system_size)
+    ops = asm.interface_local_ops(k)
+    g = asm.dirichlet_data(k, pa.capi.FN_SIN_SIN_SOL)
+    t = asm.interface_triplets(k, ops, g)
+    r, c, v, rr, rv = asm.triplets(k + 1, k, ops["lc"], ops["rhs"], g)
+    asm.synchronize()
+    assert torch.equal(t["rows"], r) and torch.equal(t["cols"], c) and torch.equal(t["vals"], v)
+    assert torch.equal(t["rhs_rows"], rr) and torch.equal(t["rhs_vals"], rv)
+    assert t["rows_cut"].numel() == 0
+    # uncut operators of the cutHHO driver == fan quadrature + naive stabilization of the plain path
+    lc = asm.local_ops(k + 1, k, pa.QUAD_FAN, pa.STAB_NAIVE, want=("lc",))["lc"]
+    assert torch.equal(lc, ops["lc"])
