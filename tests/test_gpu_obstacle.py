@@ -219,3 +219,34 @@ def test_obstacle_end_to_end_on_gpu_operators_and_assembler(asm, N, degree):
                                  assembler_factory=lambda msh, di, in_A: GpuObstacleAssembler(asm, msh, di, in_A))
     assert iters < 50
     assert abs(err - REF[N][degree]) / REF[N][degree] < 5e-6
+
+
+def test_obstacle_entry_points_refuse_bad_input(asm):
+    """status codes instead of undefined behaviour: the obstacle assembler needs the whole mesh on the
+    context (no row slab), sizes are checked before anything is launched"""
+    import ctypes as C
+    import torch
+    import proton_amd as pa
+    L = pa.capi.lib()
+    h = asm.ctx.h
+    di, _ = pa.degree_info(0, 1)
+    asm.generate_mesh(8, 8, rows=(2, 6))                         # a slab: obstacle entry points must refuse
+    n = asm.ncells
+    z8 = torch.zeros(n, dtype=torch.uint8, device=asm.device)
+    zi = torch.zeros(n * 82, dtype=torch.int32, device=asm.device)
+    zd = torch.zeros(n * 82, dtype=torch.float64, device=asm.device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = L.pa_obstacle_triplets_batch(h, di, 0, n, p(zd), None, None, p(zd), p(z8), p(zi), p(zi), 0, p(zi), p(zi), p(zd), p(zi), p(zd))
+    assert st == 1 and b"whole mesh" in L.pa_last_error(h)
+    assert L.pa_obstacle_expand_solution(h, di, p(zd), None, p(zd), p(z8), p(zi), p(zi), 0, p(zd), p(zd)) == 1
+    asm.generate_mesh(8, 8)
+    n = asm.ncells
+    assert L.pa_obstacle_triplets_batch(h, di, 0, n + 1, p(zd), None, None, p(zd), p(z8), p(zi), p(zi), 0, p(zi), p(zi), p(zd), p(zi), p(zd)) == 1
+    assert L.pa_obstacle_triplets_batch(h, di, 0, n, None, None, None, p(zd), p(z8), p(zi), p(zi), 0, p(zi), p(zi), p(zd), p(zi), p(zd)) == 1
+    assert L.pa_obstacle_tables(h, None, p(zi), p(zi), None, None) == 1
+    bad = pa.capi.DegreeInfo(7, 9, 10)
+    assert L.pa_obstacle_triplets_batch(h, bad, 0, n, p(zd), None, None, p(zd), p(z8), p(zi), p(zi), 0, p(zi), p(zi), p(zd), p(zi), p(zd)) == 2
+    # device CSR: more than 2^31 - 1 slots cannot be indexed by its int32 tables
+    nnz = C.c_size_t(0)
+    assert L.pa_csr_from_triplets(h, 1 << 31, p(zi), p(zi), p(zd), 10, p(zd), p(zi), p(zd), C.byref(nnz)) == 1
+    assert L.pa_take_local_data_batch(h, di, 0, n + 5, p(zd), None, p(zd)) == 1
