@@ -99,6 +99,9 @@ struct pa_context {
     // interface_assembler tables (cuthho_square.cpp:1137-1185)
     int32_t *d_if_cell_table = nullptr, *d_if_face_table = nullptr;
     size_t if_num_all_cells = 0, if_num_other_faces = 0;
+    // records of the per-cell pre-pass (hho_pre.hpp), grown on demand, reused by every local-operator call
+    double *d_pre = nullptr;
+    size_t pre_capacity = 0;                  // doubles
     std::string last_error;
 };
 
@@ -249,6 +252,7 @@ int pa_context_destroy(pa_context *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     release_mesh(ctx);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+    if (ctx->d_pre) (void)hipFree(ctx->d_pre);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PA_OK;
@@ -658,14 +662,56 @@ int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int st
     const int st = select_kernel(ctx, di, quad_kind, stab_kind, n, &e, &grid);
     if (st != PA_OK) return st;
     if (n == 0) return PA_OK;
-    pa::LocalOpsArgs a;
-    a.tab = ctx->d_tab; a.points = ctx->d_points; a.ptids = ctx->d_ptids;
-    a.first = first; a.n = n;
-    a.oper = d_oper; a.data = d_data; a.stab = d_stab; a.lc = d_lc; a.info = d_info;
-    a.ablate = 0;
-    if (const char *env = std::getenv("PA_ABLATE")) a.ablate = (uint32_t)std::strtoul(env, nullptr, 0);   // profiling only
+    uint32_t ablate = 0;
+    if (const char *env = std::getenv("PA_ABLATE")) ablate = (uint32_t)std::strtoul(env, nullptr, 0);   // profiling only
     const bool split = d_data != nullptr || d_stab != nullptr;
-    PA_HIP(ctx, (split ? e->launch_split : e->launch)(a, grid, ctx->stream));
+    // Kernels that take the per-cell head from the pre-pass run in pieces of at most `piece` cells: pre-pass of a
+    // piece into the context's record buffer, then the cooperative kernel over the same cells (same stream).
+    size_t piece = n;
+    if (e->launch_pre) {
+        size_t cap_bytes = (size_t)1 << 30;                               // 1 GiB of records: 2 M cells at k = 2
+        if (const char *env = std::getenv("PA_PRE_BYTES")) cap_bytes = (size_t)std::strtoull(env, nullptr, 0);
+        const size_t per_cell = (size_t)e->pre_doubles * sizeof(double);
+        size_t max_cells = cap_bytes / per_cell;
+        if (max_cells < 4096) max_cells = 4096;
+        if (piece > max_cells) piece = max_cells & ~(size_t)4095;
+        const size_t need = piece * (size_t)e->pre_doubles;
+        if (ctx->pre_capacity < need) {
+            if (ctx->d_pre) { PA_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_pre); ctx->d_pre = nullptr; ctx->pre_capacity = 0; }
+            PA_HIP(ctx, hipMalloc((void **)&ctx->d_pre, need * sizeof(double)));
+            ctx->pre_capacity = need;
+        }
+    }
+    pa_sizes sz;
+    (void)pa_sizes_for(di, quad_kind, &sz);
+    const size_t mm = (size_t)sz.msize * (size_t)sz.msize, opn = (size_t)sz.oper_rows * (size_t)sz.msize;
+    for (size_t off = 0; off < n; off += piece) {
+        const size_t m = n - off < piece ? n - off : piece;
+        int g = grid;
+        if (m != n) {
+            const pa::KernelEntry *e2 = nullptr;
+            const int st2 = select_kernel(ctx, di, quad_kind, stab_kind, m, &e2, &g);
+            if (st2 != PA_OK) return st2;
+        }
+        pa::LocalOpsArgs a;
+        a.tab = ctx->d_tab; a.points = ctx->d_points; a.ptids = ctx->d_ptids;
+        a.first = first + off; a.n = m;
+        a.pre = nullptr;
+        if (e->launch_pre) {
+            pa::PreArgs pa_;
+            pa_.tab = ctx->d_tab; pa_.points = ctx->d_points; pa_.ptids = ctx->d_ptids;
+            pa_.first = first + off; pa_.n = m; pa_.pre = ctx->d_pre;
+            PA_HIP(ctx, e->launch_pre(pa_, ctx->stream));
+            a.pre = ctx->d_pre;
+        }
+        a.oper = d_oper ? d_oper + off * opn : nullptr;
+        a.data = d_data ? d_data + off * mm : nullptr;
+        a.stab = d_stab ? d_stab + off * mm : nullptr;
+        a.lc = d_lc ? d_lc + off * mm : nullptr;
+        a.info = d_info ? d_info + off : nullptr;
+        a.ablate = ablate;
+        PA_HIP(ctx, (split ? e->launch_split : e->launch)(a, g, ctx->stream));
+    }
     return PA_OK;
 }
 

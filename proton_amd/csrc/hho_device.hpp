@@ -37,6 +37,15 @@
 #ifndef PA_WAVES_PER_EU
 #define PA_WAVES_PER_EU 0
 #endif
+// 1: the per-cell head (geometry, cell quadrature, moments, stiffness, Cholesky of gr_lhs) comes from the
+// one-thread-per-cell pre-pass of hho_pre.hpp; 0: the cooperative kernel computes it itself (A/B builds)
+#ifndef PA_USE_PRE
+#define PA_USE_PRE 1
+#endif
+
+#ifndef PA_DIRECT_MIN
+#define PA_DIRECT_MIN 14
+#endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
 #else
@@ -89,7 +98,13 @@ struct Cfg {
     static constexpr int NQ = QUAD == QUAD_TENSOR ? NG * NG : 4 * NT;
     static constexpr int NFQ = gauss_nodes(2 * FD);           // hho.hpp:74,132,208
     static constexpr int NFP = 4 * NFQ;
-    static constexpr int NP = NQ + NFP;
+    static constexpr bool FANCY = STAB == STAB_FANCY, NAIVE = STAB == STAB_NAIVE;
+    static constexpr bool GENERAL_FANCY = FANCY && CD != RD;  // T_F is dense; otherwise T_F = [trace_F | 0]
+    // The per-cell head is taken from the pre-pass (hho_pre.hpp); the dense fancy form also needs the cell mass
+    // matrix and keeps the all-in-one kernel.
+    static constexpr bool USE_PRE = PA_USE_PRE && !GENERAL_FANCY;
+    static constexpr int NQB = USE_PRE ? 0 : NQ;              // cell points evaluated by THIS kernel
+    static constexpr int NP = NQB + NFP;
     static constexpr int NPW = 2 * RD + 1;                    // powers 0..2 recdeg
     static constexpr int NMOM = P2(2 * RD);
     static constexpr int CPW = 64 / G;                        // cells per wavefront
@@ -104,9 +119,19 @@ struct Cfg {
     static constexpr bool HAS_STAB = STAB != STAB_NONE;
     // lc-only path: accumulators -> HBM directly (no LDS image) where the matrix is big enough for the
     // 128-byte runs to pay (measured: -5 % at msize 14, -2 % at 22, -1 % at 31, but +19 % at msize 9)
-    static constexpr bool DIRECT_STORE = CBS + 4 * FBS >= 14;
-    static constexpr bool FANCY = STAB == STAB_FANCY, NAIVE = STAB == STAB_NAIVE;
-    static constexpr bool GENERAL_FANCY = FANCY && CD != RD;  // T_F is dense; otherwise T_F = [trace_F | 0]
+    static constexpr bool DIRECT_STORE = CBS + 4 * FBS >= PA_DIRECT_MIN;
+
+    // ---- record of a cell written by the pre-pass (doubles): packed lower triangle of L = chol(gr_lhs), row-major,
+    // TRUE diagonal | 1/diagonal | pad | sqrt(|F|/2h) x 4, barycenter, 2/h_T, pivot status, the 4 vertices, face
+    // orientation bits (bit f: the first vertex of local face f has the HIGHER point id), pad
+    struct Pre {
+        static constexpr int NL = (RBS - 1) * RBS / 2;
+        static constexpr int oSCAL = (NL + (RBS - 1) + 1) & ~1;
+        static constexpr int NSCAL = 18;
+        static constexpr int NPRE = oSCAL + NSCAL;
+        static constexpr int NP2 = NPRE / 2;                  // 16-byte pairs
+    };
+    static constexpr int PLC = cdiv(Pre::NP2, G);             // pairs of the record per lane
 
     // ---- LDS map (doubles, per cell).  Every vector that is read as a contiguous run starts at
     // an even offset and has an even stride, so the reads are 16-byte ds_read_b128.
@@ -117,17 +142,19 @@ struct Cfg {
     // region Q: quadrature-point tables and moments -- dead once the gr_rhs columns are in registers
     // (after S3b); Z = [Y; U] and later the output image reuse it.
     static constexpr int oWPX = 0;                            // NQ x NPW   w * bx^e
-    static constexpr int oPY = oWPX + NQ * NPW;               // NQ x NPW   by^e
-    static constexpr int oPHF = oPY + NQ * NPW;               // NFP x RBS  phi at face points
+    static constexpr int oPY = oWPX + NQB * NPW;              // NQ x NPW   by^e
+    static constexpr int oPHF = oPY + NQB * NPW;              // NFP x RBS  phi at face points
     static constexpr int oDN = (oPHF + NFP * RBS + 1) & ~1;   // NFP x NRP  (w_q/2) (grad phi . edge normal)
     static constexpr int oMOM = oDN + NFP * NRP;              // NMOM moments
-    static constexpr int endQ = oMOM + NMOM;
+    static constexpr int endQ0 = oMOM + (USE_PRE ? 0 : NMOM);
     // gr_rhs cell columns are assembled by SPC lanes each (RPP rows per lane) and meet in GRC, which
     // lies on the w*bx^e / by^e tables (dead after the moments)
     // (measured: -1.7 % at k = 2, nothing at k = 3, +1 % with 16 lanes per cell -> only for G = 32)
     static constexpr int SPC = G >= 32 ? imin(G / CBS, NR) : 1, RPP = cdiv(NR, SPC < 1 ? 1 : SPC);
-    static constexpr int oGRC = 0;                            // CBS x NRP
-    static_assert(SPC <= 1 || CBS * NRP <= 2 * NQ * NPW, "GRC must fit the dead quadrature tables");
+    // (with the pre-pass there are no such tables: GRC follows the face tables)
+    static constexpr int oGRC = USE_PRE ? endQ0 : 0;          // CBS x NRP
+    static constexpr int endQ = endQ0 + (USE_PRE && SPC > 1 ? CBS * NRP : 0);
+    static_assert(USE_PRE || SPC <= 1 || CBS * NRP <= 2 * NQ * NPW, "GRC must fit the dead quadrature tables");
     static constexpr int oZ = 0;                              // ZS x MS    (written from S5 on)
     static constexpr int oOUT = 0;                            // MS x MS    (written in S8, after the last read of Z)
     static constexpr int sizeQ = imax(imax(endQ, ZS * MS), MS * MS);
@@ -137,8 +164,16 @@ struct Cfg {
     static constexpr int oST = sizeQ | 1;
     static constexpr int oMA = (oST + LD * RBS + 1) & ~1;     // RBS x RBS  mass (general fancy); chol(M1) in place
     static constexpr int oFT = oMA + (GENERAL_FANCY ? LD * RBS : 0);     // NF x RBS trace / (|F|/2) (general fancy)
-    static constexpr int oSU = (oFT + (GENERAL_FANCY ? NF * RBS : 0) + 1) & ~1;   // 4: sqrt(|F| / 2h)
-    static constexpr int oDUMMY = oSU + 4;                    // 2: sink of masked-out stores
+    static constexpr int oSUo = (oFT + (GENERAL_FANCY ? NF * RBS : 0) + 1) & ~1;   // 4: sqrt(|F| / 2h)
+    // region P with the pre-pass: the image of L (NR x LD, row-major, true diagonal; the upper triangle and one
+    // more row are zeroed once per kernel and never written again) and the tail of the record as it comes
+    // (reciprocals, scalars), shifted so that the scalars start on a 16-byte boundary
+    static constexpr int oLGp = (sizeQ + 1) & ~1;
+    static constexpr int oLIN = ((oLGp + RBS * LD + 1) & ~1) + ((Pre::oSCAL - Pre::NL) & 1);
+    static constexpr int oRCP = oLIN;                         // NR: 1 / L[i][i]
+    static constexpr int oSU = USE_PRE ? oLIN + (Pre::oSCAL - Pre::NL) : oSUo;
+    static constexpr int oLG = USE_PRE ? oLGp : oST + 1 + LD;  // chol(gr_lhs): stiff[1:,1:] in place without the pre-pass
+    static constexpr int oDUMMY = oSU + (USE_PRE ? Pre::NSCAL : 4);    // 2: sink of masked-out stores
     static constexpr int LDS_PER_CELL = (oDUMMY + 2 + 1) & ~1;
     static constexpr int LDS_DOUBLES = CPW * LDS_PER_CELL;
 };
@@ -148,6 +183,7 @@ struct LocalOpsArgs {
     const double *points;      // np x 2
     const uint32_t *ptids;     // nc x 4
     size_t first, n;
+    const double *pre;         // n records of Cfg::Pre::NPRE doubles (hho_pre.hpp), cell first+i at i * NPRE; Cfg::USE_PRE only
     double *oper, *data, *stab, *lc;
     int32_t *info;
     // Stage mask, 0 in production.  Profiling (PA_ABLATE): bit i skips stage i and the results are garbage.
@@ -198,6 +234,12 @@ __device__ __forceinline__ double fast_sqrt(double x)
     const double r = __builtin_fma(-s, s, x);
     return __builtin_fma(0.5 * y, r, s);
 }
+
+// Synchronisation of the ONE wavefront of a block on its LDS data.  LDS instructions of a wavefront execute in
+// order, so a later read by any lane sees an earlier write by any other: what is needed is that the compiler
+// keeps the order, not s_barrier -- and not what __syncthreads() adds to it, a wait for every outstanding global
+// store (vmcnt(0)): with it each cell ended with the wavefront idle until HBM had acknowledged its local matrix.
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // 16-byte LDS read of two consecutive doubles (p is 16-byte aligned by construction of the LDS map)
 __device__ __forceinline__ double2 lds_pair(const double *p) { return *reinterpret_cast<const double2 *>(p); }
@@ -287,7 +329,7 @@ __device__ __forceinline__ int lds_cholesky(double *A, int l)
         const double r = fast_rsqrt<RSQ_ITERS>(d);   // seed 2^-26 -> ~3e-16 after one Newton step
         row[j] = s * r;
         if (act && l >= j) A[i * LD + j] = (l == j) ? r : row[j];
-        __syncthreads();
+        wave_sync();
     }
     return bad;
 }
@@ -380,7 +422,7 @@ __device__ __forceinline__ int lds_cholesky_blocked(double *A, int l)
 #pragma unroll
         for (int c = 0; c < NB; ++c)
             if (c < nb && act && l >= j0 + c) A[i * LD + j0 + c] = (l == j0 + c) ? rd[c] : row[j0 + c];
-        __syncthreads();
+        wave_sync();
     }
     return bad;
 }
@@ -404,6 +446,28 @@ __device__ __forceinline__ void lds_backward(const double *L, double (&x)[N])
 #pragma unroll
         for (int k = i + 1; k < N; ++k) s -= L[k * LD + i] * x[k];
         x[i] = s * L[i * LD + i];
+    }
+}
+
+// the same with the TRUE diagonal in L and the reciprocals in rd (the image the pre-pass delivers)
+template <int N, int LD>
+__device__ __forceinline__ void lds_forward_rd(const double *L, const double *rd, double (&x)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double s = i == 0 ? x[0] : lds_dotsub_n(x[i], L + i * LD, x, i);
+        x[i] = s * rd[i];
+    }
+}
+template <int N, int LD>
+__device__ __forceinline__ void lds_backward_rd(const double *L, const double *rd, double (&x)[N])
+{
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        double s = x[i];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) s -= L[k * LD + i] * x[k];
+        x[i] = s * rd[i];
     }
 }
 
@@ -486,7 +550,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
     for (int r = 0; r < C::PPL; ++r) {
         const int p = l + r * G;
         r0[r] = r1[r] = r2[r] = rw[r] = 0.0;
-        if (p < NQ) {
+        if (C::NQB > 0 && p < C::NQB) {
             if (C::QUAD == QUAD_TENSOR) {
                 const int i = p % C::NG, j = p / C::NG;            // outer eta, inner xi  quadratures.hpp:355-357
                 r0[r] = tab->gauss_x[C::NG][i];
@@ -501,7 +565,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                 rw[r] = tab->dun[R][row][3];
             }
         } else if (p < NP) {
-            const int q = (p - NQ) % NFQ;
+            const int q = (p - C::NQB) % NFQ;
             r0[r] = tab->gauss_x[NFQ][q];
             rw[r] = 0.5 * tab->gauss_w[NFQ][q];
         }
@@ -549,7 +613,54 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
 #pragma unroll
     for (int j = 0; j < FBS; ++j) ufc[j] = tab->face[C::FD].lft[j][kf];
 
+    // pairs of the cell's pre-pass record this lane moves to LDS, and where their two doubles go
+    typedef typename C::Pre PRE;
+    int pre_dst[C::PLC][2];
+#pragma unroll
+    for (int t = 0; t < C::PLC; ++t) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = 2 * (l + t * G) + h;
+            int dst = C::oDUMMY + h;
+            if (e < PRE::NL) {
+                int i = 0;
+                while ((i + 1) * (i + 2) / 2 <= e) ++i;
+                dst = C::oLG + i * LD + (e - i * (i + 1) / 2);
+            } else if (e < PRE::NPRE) {
+                dst = C::oLIN + (e - PRE::NL);
+            }
+            pre_dst[t][h] = dst;
+        }
+    }
+
+    // The record of a cell is fetched one cell ahead: the loads are issued at the top of a cell's pass, land in
+    // registers while S1-S6 run, and go to region P when S6 is done with it -- before the stores of S8 are
+    // issued, so that no load ever queues behind them (vector memory operations complete in order).
+    double2 rec[C::PLC];
     const size_t stride = (size_t)gridDim.x * C::CPW;
+    auto rec_issue = [&](size_t b) {
+        const double *pc = a.pre + (b + g < a.n ? b + g : a.n - 1) * (size_t)PRE::NPRE;
+#pragma unroll
+        for (int t = 0; t < C::PLC; ++t) {
+            const int e2 = l0 + t * G;
+            rec[t] = *reinterpret_cast<const double2 *>(pc + 2 * (e2 < PRE::NP2 ? e2 : 0));
+        }
+    };
+    auto rec_deposit = [&]() {
+#pragma unroll
+        for (int t = 0; t < C::PLC; ++t) {
+            S[pre_dst[t][0]] = rec[t].x;
+            S[pre_dst[t][1]] = rec[t].y;
+        }
+    };
+    if (C::USE_PRE) {
+        for (int e = l; e < RBS * LD; e += G) S[C::oLG + e] = 0.0;
+        wave_sync();
+        rec_issue((size_t)blockIdx.x * C::CPW);
+        rec_deposit();
+        wave_sync();
+    }
+
     for (size_t base = (size_t)blockIdx.x * C::CPW; base < a.n; base += stride) {
         // Re-derive the lane index opaquely per cell: otherwise LICM hoists the index computations
         // of every stage out of the cell loop and the kernel spills.
@@ -560,14 +671,26 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
 
         // ================= S0: geometry (every lane of the group, registers) ==========
         PA_MARK("S0");
-        const uint4 idv = *reinterpret_cast<const uint4 *>(a.ptids + 4 * cell);
-        const double2 q0 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.x);
-        const double2 q1 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.y);
-        const double2 q2 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.z);
-        const double2 q3 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.w);
-        const double px0 = q0.x, py0 = q0.y, px1 = q1.x, py1 = q1.y, px2 = q2.x, py2 = q2.y, px3 = q3.x, py3 = q3.y;
-        double barx, bary;                          // barycenter  basic_geom.hpp:247-270
+        uint4 idv = {0u, 0u, 0u, 0u};
+        double px0 = 0.0, py0 = 0.0, px1 = 0.0, py1 = 0.0, px2 = 0.0, py2 = 0.0, px3 = 0.0, py3 = 0.0;
+        double barx, bary, ih;
+        double e0x = 0.0, e0y = 0.0, e1x = 0.0, e1y = 0.0, e2x = 0.0, e2y = 0.0, e3x = 0.0, e3y = 0.0;
+        int bad_pre = 0;
+        if (C::USE_PRE) {
+            // the per-cell head comes from the pre-pass; its record is in region P already (prefetched)
+            rec_issue(base + stride);
+            const double2 bb = lds_pair(S + C::oSU + 4), ib = lds_pair(S + C::oSU + 6);
+            barx = bb.x; bary = bb.y; ih = ib.x; bad_pre = (int)ib.y;
+        } else {
+        idv = *reinterpret_cast<const uint4 *>(a.ptids + 4 * cell);
         {
+            const double2 q0 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.x);
+            const double2 q1 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.y);
+            const double2 q2 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.z);
+            const double2 q3 = *reinterpret_cast<const double2 *>(a.points + 2 * (size_t)idv.w);
+            px0 = q0.x; py0 = q0.y; px1 = q1.x; py1 = q1.y; px2 = q2.x; py2 = q2.y; px3 = q3.x; py3 = q3.y;
+        }
+        {                                           // barycenter  basic_geom.hpp:247-270
             const double ax = px1 - px0, ay = py1 - py0, bx = px2 - px0, by = py2 - py0;
             const double cx = px3 - px0, cy = py3 - py0;
             const double d1 = (ax * by - ay * bx) * 0.5, d2 = (bx * cy - by * cx) * 0.5;
@@ -576,8 +699,8 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
             barx = px0 + rx * iden; bary = py0 + ry * iden;
         }
         // edge vectors in cell (CCW) order, squared lengths of edges and diagonals
-        const double e0x = px1 - px0, e0y = py1 - py0, e1x = px2 - px1, e1y = py2 - py1;
-        const double e2x = px3 - px2, e2y = py3 - py2, e3x = px0 - px3, e3y = py0 - py3;
+        e0x = px1 - px0; e0y = py1 - py0; e1x = px2 - px1; e1y = py2 - py1;
+        e2x = px3 - px2; e2y = py3 - py2; e3x = px0 - px3; e3y = py0 - py3;
         const double s0 = e0x * e0x + e0y * e0y, s1 = e1x * e1x + e1y * e1y;
         const double s2 = e2x * e2x + e2y * e2y, s3 = e3x * e3x + e3y * e3y;
         double h2;                                  // diameter^2  basic_geom.hpp:288-305
@@ -587,7 +710,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
             h2 = fmax(h2, fmax(d02x * d02x + d02y * d02y, d13x * d13x + d13y * d13y));
         }
         const double rh = fast_rsqrt(h2);           // 1 / h_T
-        const double ih = 2.0 * rh;                 // bx = (x - bar)/(h/2), ih = 2/h  bases.hpp:98-99,142
+        ih = 2.0 * rh;                              // bx = (x - bar)/(h/2), ih = 2/h  bases.hpp:98-99,142
         double hinv = rh;                           // fancy: h = cell diameter  hho.hpp:201
         if (C::NAIVE) {                             // naive: h = cell area      hho.hpp:119, basic_geom.hpp:317-334
             const double ux = px1 - px0, uy = py1 - py0, vx = px2 - px0, vy = py2 - py0;
@@ -600,6 +723,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
             const double len = sq * fast_rsqrt(sq);
             S[C::oSU + l] = fast_sqrt(0.5 * len * hinv);
         }
+        }
 
         // ================= S1: evaluation points ======================================
         PA_MARK("S1");
@@ -609,7 +733,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
             const int p = l + r * G;
             if (p < NP) {
                 double x, y, w, wnx = 0.0, wny = 0.0;
-                const bool is_cell = p < NQ;
+                const bool is_cell = C::NQB > 0 && p < C::NQB;      // (the opaque lane index has no known sign)
                 if (is_cell) {
                     if (C::QUAD == QUAD_TENSOR) {
                         // bilinear map and |det J| (quadratures.hpp:331-352) with the shape functions
@@ -635,16 +759,26 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                         w = tarea * rw[r];
                     }
                 } else {
-                    const int f = (p - NQ) / NFQ;
-                    const double ax = sel4(px0, px1, px2, px3, f), ay = sel4(py0, py1, py2, py3, f);
-                    const double bx = sel4(px1, px2, px3, px0, f), by = sel4(py1, py2, py3, py0, f);
-                    const uint32_t ia = sel4u(idv.x, idv.y, idv.z, idv.w, f), ib = sel4u(idv.y, idv.z, idv.w, idv.x, f);
+                    const int f = (p - C::NQB) / NFQ;
+                    double ax, ay, bx, by;
+                    bool descending;                               // the face's first vertex has the higher point id
+                    if (C::USE_PRE) {
+                        const double *sc = S + C::oSU;
+                        const double2 pa_ = lds_pair(sc + 8 + 2 * f), pb_ = lds_pair(sc + 8 + 2 * ((f + 1) & 3));
+                        ax = pa_.x; ay = pa_.y; bx = pb_.x; by = pb_.y;
+                        descending = (((int)sc[16]) >> f) & 1;
+                    } else {
+                        ax = sel4(px0, px1, px2, px3, f); ay = sel4(py0, py1, py2, py3, f);
+                        bx = sel4(px1, px2, px3, px0, f); by = sel4(py1, py2, py3, py0, f);
+                        const uint32_t ia = sel4u(idv.x, idv.y, idv.z, idv.w, f), ib = sel4u(idv.y, idv.z, idv.w, idv.x, f);
+                        descending = ia > ib;
+                    }
                     // w n = (w_q |F|/2) (e_y, -e_x)/|F|: the edge length cancels  (basic_geom.hpp:361-369,
                     // quadratures.hpp:426); rw holds w_q / 2
                     wnx = rw[r] * (by - ay); wny = -rw[r] * (bx - ax);
                     // the face runs from its LOWER-id endpoint (basic_geom.hpp:202-203, bases.hpp:260-261):
                     // its q-th point sits at -t_q in cell order when the ids are descending
-                    const double t = (ia > ib) ? -r0[r] : r0[r];
+                    const double t = descending ? -r0[r] : r0[r];
                     x = 0.5 * (1 - t) * ax + 0.5 * (1 + t) * bx;   // quadratures.hpp:420-428
                     y = 0.5 * (1 - t) * ay + 0.5 * (1 + t) * by;
                     w = 0.0;
@@ -661,7 +795,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                     }
                 } else {
                     // scaled monomials and weighted normal derivatives at a face point  bases.hpp:93-184, hho.hpp:77-83
-                    const int pf = p - NQ;
+                    const int pf = p - C::NQB;
                     double pwx[RD + 1], pwy[RD + 1];
                     pwx[0] = 1.0; pwy[0] = 1.0;
 #pragma unroll
@@ -685,10 +819,11 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
             }
         }
         }
-        __syncthreads();
+        wave_sync();
 
         // ================= S2: cell moments ===========================================
         PA_MARK("S2");
+        if (!C::USE_PRE) {
         if (!(a.ablate & 2u)) {   // S2
 #pragma unroll
         for (int t = 0; t < C::MPL; ++t) {
@@ -700,11 +835,12 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
             }
         }
         }
-        __syncthreads();
+        wave_sync();
+        }
 
         // ================= S3: stiffness (+mass) from moments ========================
         PA_MARK("S3");
-        {
+        if (!C::USE_PRE) {
             const double ih2 = ih * ih;
 #pragma unroll
             for (int t = 0; t < C::SPL; ++t) {
@@ -729,8 +865,8 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                     S[C::oMA + (e % RBS) + (e / RBS) * LD] = S[C::oMOM + mono_index(ai + aj, bi + bj)];
                 }
             }
+            wave_sync();
         }
-        __syncthreads();
 
         // ================= S3b: column c of gr_rhs  hho.hpp:64-85 =====================
         PA_MARK("S3b");
@@ -749,7 +885,8 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                 const int part = l / CBS, cc = l % CBS, r0 = part * RPP;
                 double acc[RPP];
 #pragma unroll
-                for (int r = 0; r < RPP; ++r) acc[r] = S[C::oST + 1 + (r0 + r < NR ? r0 + r : NR - 1) + cc * LD];
+                for (int r = 0; r < RPP; ++r)
+                    acc[r] = C::USE_PRE ? 0.0 : S[C::oST + 1 + (r0 + r < NR ? r0 + r : NR - 1) + cc * LD];
 #pragma unroll
                 for (int pf = 0; pf < NFP; ++pf) {
                     const double ph = S[C::oPHF + pf * RBS + cc];
@@ -762,13 +899,18 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                     if (r0 + r < NR) S[C::oGRC + cc * NRP + r0 + r] = acc[r];
             }
         } else if (l < CBS) {
-            const double *stc = S + C::oST + 1 + c * LD;
+            if (C::USE_PRE) {
 #pragma unroll
-            for (int i = 0; i + 1 < NR; i += 2) {
-                const double2 v = lds_pair(stc + i);
-                col[i] = v.x; col[i + 1] = v.y;
+                for (int i = 0; i < NR; ++i) col[i] = 0.0;
+            } else {
+                const double *stc = S + C::oST + 1 + c * LD;
+#pragma unroll
+                for (int i = 0; i + 1 < NR; i += 2) {
+                    const double2 v = lds_pair(stc + i);
+                    col[i] = v.x; col[i + 1] = v.y;
+                }
+                if (NR & 1) col[NR - 1] = stc[NR - 1];
             }
-            if (NR & 1) col[NR - 1] = stc[NR - 1];
 #pragma unroll
             for (int pf = 0; pf < NFP; ++pf) {
                 const double ph = S[C::oPHF + pf * RBS + c];
@@ -799,7 +941,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                 if (NR & 1) col[NR - 1] = __builtin_fma(dn[NR - 1], fbq[q], col[NR - 1]);
             }
         }
-        __syncthreads();
+        wave_sync();
         if (SPC > 1 && l < CBS && !(a.ablate & 4u)) {
             const double *gc = S + C::oGRC + c * NRP;
 #pragma unroll
@@ -812,12 +954,26 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
 
         // ================= S4/S5: L L^T = gr_lhs (in place in ST[1:,1:]) ; Y = L^-1 gr_rhs  hho.hpp:63,92
         PA_MARK("S4");
-        double *LG = S + C::oST + 1 + LD;        // stiff[1:,1:], symmetric: row-major == column-major
-        int bad = 0;
+        double *LG = S + C::oLG;                 // without the pre-pass: stiff[1:,1:], symmetric: row-major == column-major
+        int bad = bad_pre;
         // blocked form where its extra registers are free (measured: -3 % at k = 1; +4 % at k = 2, where it
         // pushes the kernel into spills)
-        if (!(a.ablate & 8u)) bad = NR <= 6 ? lds_cholesky_blocked<NR, LD, G>(LG, l) : lds_cholesky<NR, LD, G>(LG, l);
-        if (!(a.ablate & 16u)) lds_forward<NR, LD>(LG, col);
+        if (!C::USE_PRE && !(a.ablate & 8u)) bad = NR <= 6 ? lds_cholesky_blocked<NR, LD, G>(LG, l) : lds_cholesky<NR, LD, G>(LG, l);
+        if (C::USE_PRE) {
+            if (!(a.ablate & 16u)) {
+                lds_forward_rd<NR, LD>(LG, S + C::oRCP, col);
+                // cell column c >= 1: gr_rhs[:, c] = stiff[1:, c] - F_c and L^-1 stiff[1:, c] = L^T e_(c-1): add row c-1 of L
+                // (the image is zero above the diagonal; the other columns add its zero row NR)
+                const double *lr = LG + ((l >= 1 && l < CBS) ? l - 1 : NR) * LD;
+#pragma unroll
+                for (int i = 0; i + 1 < NR; i += 2) {
+                    const double2 v = lds_pair(lr + i);
+                    col[i] += v.x;
+                    col[i + 1] += v.y;
+                }
+                if (NR & 1) col[NR - 1] += lr[NR - 1];
+            }
+        } else if (!(a.ablate & 16u)) lds_forward<NR, LD>(LG, col);
         // The trace columns are formed only now (not next to the gr_rhs columns in S3b): they stay
         // out of the register budget of the factorization.  They read the face tables of region Q,
         // which Z overwrites: Y goes to LDS after the barrier below.
@@ -845,7 +1001,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                 for (int r = 0; r < NF; ++r) S[C::oFT + r + m * NF] = ucol[r];
             }
         }
-        __syncthreads();
+        wave_sync();
         if (l < MS) {
 #pragma unroll
             for (int k = 0; k < NR; ++k) S[C::oZ + k + c * ZS] = col[k];
@@ -855,7 +1011,8 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
 #pragma unroll
         for (int k = 0; k < NR; ++k) ycol[k] = col[k];
         if (C::GENERAL_FANCY || a.oper != nullptr) {
-            lds_backward<NR, LD>(LG, col);                 // col = oper[:, c]
+            if (C::USE_PRE) lds_backward_rd<NR, LD>(LG, S + C::oRCP, col);
+            else lds_backward<NR, LD>(LG, col);            // col = oper[:, c]
             if (a.oper != nullptr && valid && l < MS) {
                 double *dst = a.oper + (cell - a.first) * (size_t)(NR * MS) + (size_t)c * NR;
 #pragma unroll
@@ -876,7 +1033,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                     for (int k = 0; k < NR; ++k) s += S[C::oMA + i + (1 + k) * LD] * col[k];
                     pr[i] = s;
                 }
-                __syncthreads();
+                wave_sync();
                 const int badm = lds_cholesky<CBS, LD, G>(S + C::oMA, l);
                 if (badm && !bad) bad = 100 + badm;
                 lds_forward<CBS, LD>(S + C::oMA, pr);
@@ -917,7 +1074,8 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                 for (int r = 0; r < NF; ++r) S[C::oZ + NRP + r + c * ZS] = ucol[r];
             }
         }
-        __syncthreads();
+        wave_sync();
+        if (C::USE_PRE) rec_deposit();      // region P is free (L, reciprocals, scalars all consumed): next cell's record
 
         // ================= S7/S8 (lc only): lc = Z^T Z on the matrix pipe ============
         // v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) B(4x16); lane l supplies A[l&15][l>>4] and
@@ -934,7 +1092,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
             const int kk = lane >> 4, jj = lane & 15;
             // no barrier is needed between the cells: the wavefront reads a cell's Z and then overwrites
             // it with the same cell's output image in program order
-            __syncthreads();      // Z complete (all columns written)
+            wave_sync();      // Z complete (all columns written)
 #pragma unroll
             for (int gi = 0; gi < C::CPW; ++gi) {
                 v4d acc[NPAIRS];
@@ -1012,10 +1170,10 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                 }
             }
             if (C::DIRECT_STORE) {
-                __syncthreads();      // the next cell's tables overwrite Z
+                wave_sync();      // the next cell's tables overwrite Z
             } else {
                 if (a.lc != nullptr && !(a.ablate & 128u)) {
-                    __syncthreads();
+                    wave_sync();
                     if (valid) {
                         double *o = a.lc + (cell - a.first) * (size_t)(MS * MS);
                         constexpr int NPAIR = MS * MS / 2;
@@ -1032,7 +1190,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                         }
                     }
                 }
-                __syncthreads();
+                wave_sync();
             }
         } else {
         // ================= S7: lc = Z^T Z, entries (c, c + d mod MS) ==================
@@ -1059,7 +1217,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                 cp = (cp + 1 == MS) ? 0 : cp + 1;
             }
         }
-        __syncthreads();      // every read of L and Z is done: the output image may overwrite Z
+        wave_sync();      // every read of L and Z is done: the output image may overwrite Z
 
         // ================= S8: mirror through LDS, stream to HBM ======================
         PA_MARK("S8");
@@ -1078,7 +1236,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                     cp = (cp + 1 == MS) ? 0 : cp + 1;
                 }
             }
-            __syncthreads();
+            wave_sync();
             if (valid) {
                 double *o = dst + (cell - a.first) * (size_t)(MS * MS);
                 constexpr int NPAIR = MS * MS / 2;
@@ -1094,7 +1252,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                     if (l == 0) o[MS * MS - 1] = S[C::oOUT + MS * MS - 1];
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
         }
         if (valid && a.info != nullptr && l == 0) a.info[cell - a.first] = bad;

@@ -15,7 +15,9 @@
      (const void *)&pa::hho_local_ops_kernel<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, false>,        \
      (int)(pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::LDS_DOUBLES * sizeof(double)),                  \
      "hho_local_ops<cd=" PA_STR(PA_CD) ",fd=" PA_STR(PA_FD) ",quad=" PA_STR(PA_QUAD) ",stab=" #STAB ",G=" #G ">",                \
-     pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::WAVES}
+     pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::WAVES,                                                \
+     pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::USE_PRE ? &pa::launch_pre<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>> : nullptr, \
+     pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::Pre::NPRE}
 #define PA_ENTRIES_G(G) PA_ENTRY(0, G), PA_ENTRY(1, G), PA_ENTRY(2, G)
 
 static const pa::KernelEntry k_entries[] = {

@@ -2,10 +2,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "hho_device.hpp"
+#include "hho_pre.hpp"
 
 namespace pa {
 
 typedef hipError_t (*local_ops_launcher)(const LocalOpsArgs &, int grid, hipStream_t);
+typedef hipError_t (*pre_launcher)(const PreArgs &, hipStream_t);
 
 struct KernelEntry {
     int cd, fd, quad, stab, lanes_per_cell;
@@ -15,12 +17,21 @@ struct KernelEntry {
     int lds_bytes;
     const char *name;
     int waves_per_simd;        // the occupancy the instance is tuned for (Cfg::WAVES): the grid does not exceed it
+    pre_launcher launch_pre;   // the one-thread-per-cell pre-pass the kernel consumes (nullptr: all-in-one kernel)
+    int pre_doubles;           // doubles per cell of its record (Cfg::Pre::NPRE)
 };
 
 template <class C, bool SPLIT>
 hipError_t launch_local_ops(const LocalOpsArgs &a, int grid, hipStream_t s)
 {
     hipLaunchKernelGGL((hho_local_ops_kernel<C, SPLIT>), dim3(grid), dim3(64), C::LDS_DOUBLES * sizeof(double), s, a);
+    return hipGetLastError();
+}
+
+template <class C>
+hipError_t launch_pre(const PreArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL((hho_cell_pre_kernel<C>), dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
