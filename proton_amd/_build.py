@@ -27,7 +27,7 @@ if os.environ.get("PA_WAVES_PER_EU"):      # tuning knob: register budget of the
 # the AMDGPU register-pressure trackers cut the spills of these three instances (k = 2 tensor: 56 -> 26
 # spilled VGPRs at 4 waves/SIMD, which then beats 3 waves by 2 %); they hurt the (0,1) and (4,3) ones.
 PER_CONFIG_FLAGS = {
-    (3, 2, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
+    (3, 2, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_DIRECT_MIN=99"],      # lc through the LDS image: -3 % here
     (3, 2, 1): ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
     (2, 1, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_WAVES_PER_EU=4"],
 }

@@ -675,7 +675,7 @@ int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int st
         size_t max_cells = cap_bytes / per_cell;
         if (max_cells < 4096) max_cells = 4096;
         if (piece > max_cells) piece = max_cells & ~(size_t)4095;
-        const size_t need = piece * (size_t)e->pre_doubles;
+        const size_t need = ((piece + 7) / 8) * 8 * (size_t)e->pre_doubles;      // whole tiles of 8 records
         if (ctx->pre_capacity < need) {
             if (ctx->d_pre) { PA_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_pre); ctx->d_pre = nullptr; ctx->pre_capacity = 0; }
             PA_HIP(ctx, hipMalloc((void **)&ctx->d_pre, need * sizeof(double)));
@@ -710,7 +710,29 @@ int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int st
         a.lc = d_lc ? d_lc + off * mm : nullptr;
         a.info = d_info ? d_info + off : nullptr;
         a.ablate = ablate;
+        a.dbg = nullptr;
+#ifdef PA_STAGE_CLOCK
+        // diagnostic build: per-stage shader clocks of the cooperative kernel, averaged over blocks, to stderr
+        static long long *d_dbg = nullptr;
+        const size_t ndbg = (size_t)g * PA_NSTAGE;
+        if (!d_dbg) (void)hipMalloc((void **)&d_dbg, (size_t)(1 << 20) * sizeof(long long));
+        (void)hipMemsetAsync(d_dbg, 0, ndbg * sizeof(long long), ctx->stream);
+        a.dbg = d_dbg;
+#endif
         PA_HIP(ctx, (split ? e->launch_split : e->launch)(a, g, ctx->stream));
+#ifdef PA_STAGE_CLOCK
+        {
+            std::vector<long long> h(ndbg);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpy(h.data(), d_dbg, ndbg * sizeof(long long), hipMemcpyDeviceToHost);
+            double sum[PA_NSTAGE] = {0};
+            for (int b = 0; b < g; ++b) for (int i = 0; i < PA_NSTAGE; ++i) sum[i] += (double)h[(size_t)b * PA_NSTAGE + i];
+            const double iters = (double)m / (64 / e->lanes_per_cell);
+            std::fprintf(stderr, "PA_STAGE_CLOCK %s grid %d: clocks per wave pass:", e->name, g);
+            for (int i = 0; i < PA_NSTAGE; ++i) std::fprintf(stderr, " s%d=%.0f", i, sum[i] / iters);
+            std::fprintf(stderr, "\n");
+        }
+#endif
     }
     return PA_OK;
 }

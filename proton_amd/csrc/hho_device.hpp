@@ -46,10 +46,24 @@
 #ifndef PA_DIRECT_MIN
 #define PA_DIRECT_MIN 14
 #endif
+#ifndef PA_LC_VALU
+#define PA_LC_VALU 0
+#endif
+#ifndef PA_CORNER_VALU
+#define PA_CORNER_VALU 1
+#endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
 #else
 #define PA_MARK(x)
+#endif
+// diagnostic build (-DPA_STAGE_CLOCK): shader-clock stamps at the stage boundaries, summed per block over its cells
+// and written to LocalOpsArgs::dbg[block][stage]; PA_TICK(i) closes stage i
+#ifdef PA_STAGE_CLOCK
+#define PA_NSTAGE 12
+#define PA_TICK(i) do { const long long t_ = clock64(); tk_sum[i] += t_ - tk_last; tk_last = t_; } while (0)
+#else
+#define PA_TICK(i)
 #endif
 namespace pa {
 
@@ -120,6 +134,10 @@ struct Cfg {
     // lc-only path: accumulators -> HBM directly (no LDS image) where the matrix is big enough for the
     // 128-byte runs to pay (measured: -5 % at msize 14, -2 % at 22, -1 % at 31, but +19 % at msize 9)
     static constexpr bool DIRECT_STORE = CBS + 4 * FBS >= PA_DIRECT_MIN;
+    // msize 17..24: the bottom-right tile of Z^T Z holds at most 8 x 8 useful entries and would cost the matrix pipe as
+    // much as a full one -> vector FMAs, one lane per unordered pair of its columns
+    static constexpr int NCORNER = CBS + 4 * FBS - 16;
+    static constexpr bool CORNER_VALU = PA_CORNER_VALU && NCORNER > 0 && NCORNER <= 8 && NCORNER * (NCORNER + 1) / 2 <= G;
 
     // ---- record of a cell written by the pre-pass (doubles): packed lower triangle of L = chol(gr_lhs), row-major,
     // TRUE diagonal | 1/diagonal | pad | sqrt(|F|/2h) x 4, barycenter, 2/h_T, pivot status, the 4 vertices, face
@@ -183,7 +201,7 @@ struct LocalOpsArgs {
     const double *points;      // np x 2
     const uint32_t *ptids;     // nc x 4
     size_t first, n;
-    const double *pre;         // n records of Cfg::Pre::NPRE doubles (hho_pre.hpp), cell first+i at i * NPRE; Cfg::USE_PRE only
+    const double *pre;         // records of Cfg::Pre::NPRE doubles (hho_pre.hpp) in tiles of 8 cells; Cfg::USE_PRE only
     double *oper, *data, *stab, *lc;
     int32_t *info;
     // Stage mask, 0 in production.  Profiling (PA_ABLATE): bit i skips stage i and the results are garbage.
@@ -191,6 +209,7 @@ struct LocalOpsArgs {
     // prove taken, so it does not hoist their per-lane, cell-invariant subexpressions out of the cell loop.
     // With the branches compiled out the k = 2 kernel spills 26 more VGPRs and runs 7 % slower (measured).
     uint32_t ablate;
+    long long *dbg;            // -DPA_STAGE_CLOCK builds only
 };
 
 // index of the monomial bx^p by^r in the graded ordering (total degree, then r)  bases.hpp:114-128
@@ -637,13 +656,18 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
     // registers while S1-S6 run, and go to region P when S6 is done with it -- before the stores of S8 are
     // issued, so that no load ever queues behind them (vector memory operations complete in order).
     double2 rec[C::PLC];
+    // Blocks b and b + 8 share an XCD (round-robin dispatch; a speed assumption only): give the blocks of an XCD
+    // consecutive cells, so that the 8 cells of a record tile, and the lines of lc they share, meet in one L2.
+    const size_t lblock = (gridDim.x % 8 == 0) ? (size_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (size_t)blockIdx.x;
     const size_t stride = (size_t)gridDim.x * C::CPW;
     auto rec_issue = [&](size_t b) {
-        const double *pc = a.pre + (b + g < a.n ? b + g : a.n - 1) * (size_t)PRE::NPRE;
+        // records lie in tiles of 8 cells, [tile][pair][cell % 8] (hho_pre.hpp): the pairs of one record are 128 bytes apart
+        const size_t i = b + g < a.n ? b + g : a.n - 1;
+        const double *pc = a.pre + (((i >> 3) * (size_t)PRE::NP2) * 8 + (i & 7)) * 2;
 #pragma unroll
         for (int t = 0; t < C::PLC; ++t) {
             const int e2 = l0 + t * G;
-            rec[t] = *reinterpret_cast<const double2 *>(pc + 2 * (e2 < PRE::NP2 ? e2 : 0));
+            rec[t] = *reinterpret_cast<const double2 *>(pc + 16 * (e2 < PRE::NP2 ? e2 : 0));
         }
     };
     auto rec_deposit = [&]() {
@@ -656,12 +680,15 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
     if (C::USE_PRE) {
         for (int e = l; e < RBS * LD; e += G) S[C::oLG + e] = 0.0;
         wave_sync();
-        rec_issue((size_t)blockIdx.x * C::CPW);
+        rec_issue(lblock * C::CPW);
         rec_deposit();
         wave_sync();
     }
 
-    for (size_t base = (size_t)blockIdx.x * C::CPW; base < a.n; base += stride) {
+#ifdef PA_STAGE_CLOCK
+    long long tk_sum[PA_NSTAGE] = {0}, tk_last = clock64();
+#endif
+    for (size_t base = lblock * C::CPW; base < a.n; base += stride) {
         // Re-derive the lane index opaquely per cell: otherwise LICM hoists the index computations
         // of every stage out of the cell loop and the kernel spills.
         int l = l0;
@@ -725,6 +752,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
         }
         }
 
+        PA_TICK(0);
         // ================= S1: evaluation points ======================================
         PA_MARK("S1");
         if (!(a.ablate & 1u)) {   // S1
@@ -868,6 +896,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
             wave_sync();
         }
 
+        PA_TICK(1);
         // ================= S3b: column c of gr_rhs  hho.hpp:64-85 =====================
         PA_MARK("S3b");
         const int c = l < MS ? l : 0;
@@ -953,6 +982,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
         }
 
         // ================= S4/S5: L L^T = gr_lhs (in place in ST[1:,1:]) ; Y = L^-1 gr_rhs  hho.hpp:63,92
+        PA_TICK(2);
         PA_MARK("S4");
         double *LG = S + C::oLG;                 // without the pre-pass: stiff[1:,1:], symmetric: row-major == column-major
         int bad = bad_pre;
@@ -1020,6 +1050,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
             }
         }
 
+        PA_TICK(3);
         // ================= S6: column c of U ==========================================
         PA_MARK("S6");
         if (C::HAS_STAB && !(a.ablate & 32u)) {
@@ -1075,6 +1106,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
             }
         }
         wave_sync();
+        PA_TICK(4);
         if (C::USE_PRE) rec_deposit();      // region P is free (L, reciprocals, scalars all consumed): next cell's record
 
         // ================= S7/S8 (lc only): lc = Z^T Z on the matrix pipe ============
@@ -1083,7 +1115,8 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
         // operands are elements of Z: A[i][k] = Z[k][16I+i], B[k][j] = Z[k][16J+j] -- one LDS read per
         // lane feeds 16 FMAs (the vector form reads one LDS double per FMA).  All 64 lanes work on one
         // cell at a time; the CPW cells of the wavefront are processed in turn.
-        if (!SPLIT) {
+        PA_TICK(5);
+        if (!SPLIT && !PA_LC_VALU) {
             PA_MARK("S7m");
             constexpr int NTL = (MS + 15) / 16;              // column tiles
             constexpr int KS = (C::ZR + 3) / 4;              // k-steps
@@ -1093,6 +1126,23 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
             // no barrier is needed between the cells: the wavefront reads a cell's Z and then overwrites
             // it with the same cell's output image in program order
             wave_sync();      // Z complete (all columns written)
+            // corner tile on the vector pipe: every group for its own cell, before the image may overwrite Z
+            double corner = 0.0;
+            int cic = 0, cjc = 0;
+            if (C::CORNER_VALU && l < C::NCORNER * (C::NCORNER + 1) / 2 && !(a.ablate & 64u)) {
+                while ((cjc + 1) * (cjc + 2) / 2 <= l) ++cjc;
+                cic = l - cjc * (cjc + 1) / 2;                               // cic <= cjc
+                const double *zi = S + C::oZ + (16 + cic) * ZS, *zj = S + C::oZ + (16 + cjc) * ZS;
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int k = 0; k + 1 < C::ZR; k += 2) {
+                    const double2 p = lds_pair(zi + k), q = lds_pair(zj + k);
+                    s0 = __builtin_fma(p.x, q.x, s0);
+                    s1 = __builtin_fma(p.y, q.y, s1);
+                }
+                if (C::ZR & 1) s0 = __builtin_fma(zi[C::ZR - 1], zj[C::ZR - 1], s0);
+                corner = s0 + s1;
+            }
 #pragma unroll
             for (int gi = 0; gi < C::CPW; ++gi) {
                 v4d acc[NPAIRS];
@@ -1117,9 +1167,11 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                         for (int I = 0; I < NTL; ++I)
 #pragma unroll
                             for (int J = I; J < NTL; ++J, ++t)
-                                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[I], z[J], acc[t], 0, 0, 0);
+                                if (!(C::CORNER_VALU && I == 1 && J == 1))
+                                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[I], z[J], acc[t], 0, 0, 0);
                     }
                 }
+                PA_TICK(6 + 2 * (gi & 1));
                 PA_MARK("S8m");
                 if (C::DIRECT_STORE) {
                     // ---- S8 (lc only): straight from the accumulators to HBM, no LDS image.  lc is symmetric:
@@ -1135,6 +1187,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
 #pragma unroll
                             for (int J = I; J < NTL; ++J, ++t) {
                                 const int colj = 16 * J + jj;
+                                if (C::CORNER_VALU && I == 1 && J == 1) continue;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int row = 16 * I + kk + 4 * r;
@@ -1154,7 +1207,7 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
 #pragma unroll
                         for (int J = I; J < NTL; ++J, ++t) {
                             const int colj = 16 * J + jj;
-                            if (colj < MS) {
+                            if (colj < MS && !(C::CORNER_VALU && I == 1 && J == 1)) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int row = 16 * I + kk + 4 * r;
@@ -1167,6 +1220,19 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
                             }
                         }
                 }
+                }
+                PA_TICK(7 + 2 * (gi & 1));
+            }
+            if (C::CORNER_VALU && a.lc != nullptr && !(a.ablate & 128u) && l < C::NCORNER * (C::NCORNER + 1) / 2) {
+                if (C::DIRECT_STORE) {
+                    if (valid) {
+                        double *o = a.lc + (cell - a.first) * (size_t)(MS * MS);
+                        o[(16 + cic) + (16 + cjc) * MS] = corner;
+                        o[(16 + cjc) + (16 + cic) * MS] = corner;
+                    }
+                } else {
+                    S[C::oOUT + (16 + cic) + (16 + cjc) * MS] = corner;
+                    S[C::oOUT + (16 + cjc) + (16 + cic) * MS] = corner;
                 }
             }
             if (C::DIRECT_STORE) {
@@ -1256,7 +1322,12 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
         }
         }
         if (valid && a.info != nullptr && l == 0) a.info[cell - a.first] = bad;
+        PA_TICK(10);
     }
+#ifdef PA_STAGE_CLOCK
+    if (a.dbg != nullptr && lane == 0)
+        for (int i = 0; i < PA_NSTAGE; ++i) a.dbg[(size_t)blockIdx.x * PA_NSTAGE + i] = tk_sum[i];
+#endif
 }
 
 }  // namespace pa

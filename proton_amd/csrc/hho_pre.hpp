@@ -21,7 +21,7 @@ struct PreArgs {
     const QuadTables *tab;
     const double *points;
     const uint32_t *ptids;
-    size_t first, n;           // cells first .. first+n-1; record of cell first+i at pre + i * NPRE
+    size_t first, n;           // cells first .. first+n-1; record of cell first+i: tile i / 8, slot i % 8 (see the kernel)
     double *pre;
 };
 
@@ -69,7 +69,12 @@ __global__ __launch_bounds__(64) void hho_cell_pre_kernel(PreArgs a)
         const double wx = px3 - px0, wy = py3 - py0;
         hinv = fast_rcp(fabs(ux * vy - uy * vx) * 0.5 + fabs(vx * wy - vy * wx) * 0.5);
     }
-    double *out = a.pre + i * (size_t)PL::NPRE;
+    // The records are stored in tiles of 8 cells, pair by pair: [tile][16-byte pair][cell % 8].  The 8 lanes of a
+    // tile write one full 128-byte line per store instruction (one record per lane, 496-byte stride, made every
+    // 16-byte piece its own request at the L2: 0.23 ms of the k = 2 pre-pass was that); the consumer reads a record
+    // as pairs 128 bytes apart, one cell ahead of its use.
+    double *out = a.pre + (((i >> 3) * (size_t)PL::NP2) * 8 + (i & 7)) * 2;
+    auto put = [&](int e, double2 v) { *reinterpret_cast<double2 *>(out + (e / 2) * 16) = v; };
     {
         double su[4];
         const double sq[4] = {s0, s1, s2, s3};
@@ -78,8 +83,8 @@ __global__ __launch_bounds__(64) void hho_cell_pre_kernel(PreArgs a)
             const double len = sq[f] * fast_rsqrt(sq[f]);
             su[f] = C::HAS_STAB ? fast_sqrt(0.5 * len * hinv) : 0.0;
         }
-        *reinterpret_cast<double2 *>(out + PL::oSCAL) = double2{su[0], su[1]};
-        *reinterpret_cast<double2 *>(out + PL::oSCAL + 2) = double2{su[2], su[3]};
+        put(PL::oSCAL, double2{su[0], su[1]});
+        put(PL::oSCAL + 2, double2{su[2], su[3]});
     }
 
     // ---- moments  sum_q w_q bx_q^p by_q^r,  p + r <= 2 recdeg
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(64) void hho_cell_pre_kernel(PreArgs a)
     // ---- the record
     constexpr int NL = PL::NL;
 #pragma unroll
-    for (int e = 0; e + 1 < NL; e += 2) *reinterpret_cast<double2 *>(out + e) = double2{L[e], L[e + 1]};
+    for (int e = 0; e + 1 < NL; e += 2) put(e, double2{L[e], L[e + 1]});
     {
         // the odd tail of L shares its 16 bytes with the first reciprocal
         double lin[PL::oSCAL - (NL & ~1)];
@@ -186,18 +191,18 @@ __global__ __launch_bounds__(64) void hho_cell_pre_kernel(PreArgs a)
         }
 #pragma unroll
         for (int e = 0; e + 1 < PL::oSCAL - (NL & ~1); e += 2)
-            *reinterpret_cast<double2 *>(out + (NL & ~1) + e) = double2{lin[e], lin[e + 1]};
+            put((NL & ~1) + e, double2{lin[e], lin[e + 1]});
     }
-    *reinterpret_cast<double2 *>(out + PL::oSCAL + 4) = double2{barx, bary};
-    *reinterpret_cast<double2 *>(out + PL::oSCAL + 6) = double2{ih, (double)bad};
-    *reinterpret_cast<double2 *>(out + PL::oSCAL + 8) = q0;
-    *reinterpret_cast<double2 *>(out + PL::oSCAL + 10) = q1;
-    *reinterpret_cast<double2 *>(out + PL::oSCAL + 12) = q2;
-    *reinterpret_cast<double2 *>(out + PL::oSCAL + 14) = q3;
+    put(PL::oSCAL + 4, double2{barx, bary});
+    put(PL::oSCAL + 6, double2{ih, (double)bad});
+    put(PL::oSCAL + 8, q0);
+    put(PL::oSCAL + 10, q1);
+    put(PL::oSCAL + 12, q2);
+    put(PL::oSCAL + 14, q3);
     // a face runs from its LOWER-id endpoint (basic_geom.hpp:202-203, bases.hpp:260-261): bit f = local face f is
     // traversed against that direction by the cell's CCW vertex order
     const int flags = (idv.x > idv.y ? 1 : 0) | (idv.y > idv.z ? 2 : 0) | (idv.z > idv.w ? 4 : 0) | (idv.w > idv.x ? 8 : 0);
-    *reinterpret_cast<double2 *>(out + PL::oSCAL + 16) = double2{(double)flags, 0.0};
+    put(PL::oSCAL + 16, double2{(double)flags, 0.0});
 }
 
 }  // namespace pa
