@@ -345,7 +345,9 @@ def main():
                        "note": w["note"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": li.kernel_name.decode(), "kernel_ms": kern_ms,
+                         "kernel": li.kernel_name.decode() + (" + hho_cell_pre (its one-thread-per-cell pre-pass)" if w["stab"] != "fancy" or w["cd"] == w["fd"] + 1 else ""),
+                         "kernel_ms": kern_ms,
+                         "kernel_ms_is": "HIP events around the local-operator launches of one step (pre-pass + cooperative kernel where the path is split: the sum of their rocprofv3 averages)",
                          "algorithmic_bytes_per_cell": bpc, "cells_per_launch": n_local,
                          "lanes_per_cell": li.lanes_per_cell, "grid_blocks": li.grid_blocks,
                          "lds_bytes_per_block": li.lds_bytes_per_block},

@@ -163,6 +163,35 @@ def test_batch_matches_oracle(asm, oracle, cd, fd, kind, stabname):
     assert nerr_cells(rhs2.cpu().numpy()[:, :, None], refr["rhs"][:, :, None]) < TOL
 
 
+@pytest.mark.parametrize("cd,fd,kind,stabname", [(3, 2, "tensor", "fancy"), (2, 1, "fan", "naive"), (4, 3, "tensor", "fancy")])
+def test_pre_pass_in_pieces(asm, oracle, cd, fd, kind, stabname, monkeypatch):
+    """The split path (one-thread-per-cell pre-pass + cooperative kernel, hho_pre.hpp) runs in pieces when the record
+    buffer is capped (PA_PRE_BYTES; 1 GiB by default, i.e. pieces from 1-2 M cells on): same results piece by piece,
+    bit for bit, as in one pass, and both match the oracle."""
+    import torch
+    import proton_amd as pa
+    from proton_amd.batch import to_rowcol
+    N = 96                                   # 9216 cells: 3 pieces of 4096 / 4096 / 1024 under the smallest cap
+    points, ptids = perturbed_mesh(oracle, N, seed=77 + cd)
+    asm.set_mesh(points, ptids)
+    quad = pa.QUAD_TENSOR if kind == "tensor" else pa.QUAD_FAN
+    stab = pa.STAB_FANCY if stabname == "fancy" else pa.STAB_NAIVE
+    whole = asm.local_ops(cd, fd, quad, stab, want=("oper", "lc", "info"))
+    asm.synchronize()
+    whole = {k: v.clone() for k, v in whole.items()}
+    monkeypatch.setenv("PA_PRE_BYTES", "1")  # clamps to the minimum piece (4096 cells)
+    pieces = asm.local_ops(cd, fd, quad, stab, want=("oper", "lc", "info"))
+    asm.synchronize()
+    monkeypatch.delenv("PA_PRE_BYTES")
+    for k in ("oper", "lc", "info"):
+        assert torch.equal(whole[k], pieces[k]), k
+    di = oracle.degrees(cd, fd)
+    sel = np.r_[0:64, 4090:4102, 8190:8200, 9200:9216]
+    st, ref = oracle.local_ops_batch(points, ptids[sel], di, quad, stab, want=("lc",))
+    assert st == 0
+    assert nerr_cells(to_rowcol(pieces["lc"][torch.as_tensor(sel, device=pieces["lc"].device)]), ref["lc"]) < TOL
+
+
 def test_error_codes(asm):
     import ctypes as C
     import proton_amd as pa
