@@ -1158,7 +1158,8 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
 #pragma unroll
                         for (int t = 0; t < NTL; ++t) {
                             const int col = 16 * t + jj;
-                            const bool ok = k < C::ZR && col < MS;
+                            // (decided at compile time wherever the whole tile row / k-step is inside Z)
+                            const bool ok = (4 * ks + 3 < C::ZR || k < C::ZR) && (16 * t + 15 < MS || col < MS);
                             const double v = Zg[ok ? k + col * ZS : 0];
                             z[t] = ok ? v : 0.0;
                         }
@@ -1191,7 +1192,8 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int row = 16 * I + kk + 4 * r;
-                                    if (16 * I + 4 * r < MS && valid_g && colj < MS && row < MS) {
+                                    if (16 * I + 4 * r < MS && valid_g && (16 * J + 15 < MS || colj < MS) &&
+                                        (16 * I + 4 * r + 3 < MS || row < MS)) {
                                         const double v = acc[t][r];
                                         o[colj + row * MS] = v;                 // entry (colj, row)
                                         if (I != J) o[row + colj * MS] = v;     // entry (row, colj)
@@ -1207,11 +1209,11 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
 #pragma unroll
                         for (int J = I; J < NTL; ++J, ++t) {
                             const int colj = 16 * J + jj;
-                            if (colj < MS && !(C::CORNER_VALU && I == 1 && J == 1)) {
+                            if ((16 * J + 15 < MS || colj < MS) && !(C::CORNER_VALU && I == 1 && J == 1)) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int row = 16 * I + kk + 4 * r;
-                                    if (16 * I + 4 * r < MS && row < MS) {
+                                    if (16 * I + 4 * r < MS && (16 * I + 4 * r + 3 < MS || row < MS)) {
                                         const double v = acc[t][r];
                                         Og[row + colj * MS] = v;
                                         if (I != J) Og[colj + row * MS] = v;
