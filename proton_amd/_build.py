@@ -23,13 +23,14 @@ if os.environ.get("PA_WAVES_PER_EU"):      # tuning knob: register budget of the
     FLAGS.append("-DPA_WAVES_PER_EU=" + os.environ["PA_WAVES_PER_EU"])
 
 
-# Per-instance compiler settings, each measured on the MI355X against the default:
-# the AMDGPU register-pressure trackers cut the spills of these three instances (k = 2 tensor: 56 -> 26
-# spilled VGPRs at 4 waves/SIMD, which then beats 3 waves by 2 %); they hurt the (0,1) and (4,3) ones.
+# Per-instance compiler settings, each measured on the MI355X against the default.
+# No instance may spill: a scratch reload in the store phase waits for every outstanding store (vmcnt(0)).
 PER_CONFIG_FLAGS = {
-    (3, 2, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_DIRECT_MIN=99"],      # lc through the LDS image: -3 % here
+    # k = 2 tensor: 128 VGPRs without spills since U is formed by units; lc through the LDS image (-3 %), 4 waves (-2 %)
+    (3, 2, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_DIRECT_MIN=99", "-DPA_WAVES_PER_EU=4"],
     (3, 2, 1): ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
     (2, 1, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_WAVES_PER_EU=4"],
+    (2, 1, 1): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_WAVES_PER_EU=4"],
 }
 
 

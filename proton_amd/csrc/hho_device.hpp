@@ -52,6 +52,9 @@
 #ifndef PA_CORNER_VALU
 #define PA_CORNER_VALU 1
 #endif
+#ifndef PA_UNIT_U
+#define PA_UNIT_U 1
+#endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
 #else
@@ -191,8 +194,8 @@ struct Cfg {
     static constexpr int oRCP = oLIN;                         // NR: 1 / L[i][i]
     static constexpr int oSU = USE_PRE ? oLIN + (Pre::oSCAL - Pre::NL) : oSUo;
     static constexpr int oLG = USE_PRE ? oLGp : oST + 1 + LD;  // chol(gr_lhs): stiff[1:,1:] in place without the pre-pass
-    static constexpr int oDUMMY = oSU + (USE_PRE ? Pre::NSCAL : 4);    // 2: sink of masked-out stores
-    static constexpr int LDS_PER_CELL = (oDUMMY + 2 + 1) & ~1;
+    static constexpr int oDUMMY = oSU + (USE_PRE ? Pre::NSCAL : 4);    // 4: sink of masked-out stores
+    static constexpr int LDS_PER_CELL = (oDUMMY + 4 + 1) & ~1;
     static constexpr int LDS_DOUBLES = CPW * LDS_PER_CELL;
 };
 
@@ -1010,10 +1013,38 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
         // trace columns / (|F|/2):  tr[fk] = sum_q w_q t_q^k phi_c(x_fq)   hho.hpp:209-216 / 133-140.
         // Point q of face f IS the reference's q-th face point (S1 mirrors t for faces whose lower-id
         // endpoint comes second), so its face-basis value is t_q^k for either orientation.
+        // lc only, T_F = [trace_F | 0]: the cell part of U is formed by UNITS (face f, cell column cc), one lane each --
+        // 4 CBS units of FBS entries (trace, L^^-1, scale) instead of every column lane carrying all NF rows of its
+        // column through the same steps with CBS of G lanes useful; the face columns of U are -sqrt(|F|/2h) L^^T E_F,
+        // constants times the face's scale.  Nothing of U is held in registers across the stages.
+        constexpr bool UNIT_U = C::HAS_STAB && !C::GENERAL_FANCY && !SPLIT && PA_UNIT_U;
+        constexpr int NU = 4 * CBS, UR = UNIT_U ? cdiv(NU, G) : 1;
+        double uval[UR][FBS];
+        if (UNIT_U && !(a.ablate & 32u)) {
+#pragma unroll
+            for (int r = 0; r < UR; ++r) {
+                const int u = l + r * G;
+                const int uu = ((r + 1) * G <= NU || u < NU) ? u : 0;
+                const int f = uu / CBS, cc = uu - f * CBS;
+                double x[FBS];
+#pragma unroll
+                for (int k = 0; k < FBS; ++k) x[k] = 0.0;
+#pragma unroll
+                for (int q = 0; q < NFQ; ++q) {
+                    const double ph = S[C::oPHF + (f * NFQ + q) * RBS + cc];
+#pragma unroll
+                    for (int k = 0; k < FBS; ++k) x[k] += ft.cw[q][k] * ph;
+                }
+                face_forward<FBS>(ft, x);
+                const double su = S[C::oSU + f];
+#pragma unroll
+                for (int k = 0; k < FBS; ++k) uval[r][k] = su * x[k];
+            }
+        }
         double ucol[C::HAS_STAB ? NF : 1];
 #pragma unroll
         for (int r = 0; r < (C::HAS_STAB ? NF : 1); ++r) ucol[r] = 1.0;
-        if (C::HAS_STAB && !(a.ablate & 32u)) {
+        if (C::HAS_STAB && !UNIT_U && !(a.ablate & 32u)) {
             constexpr int TCOLS = C::GENERAL_FANCY ? RBS : CBS;
             const int m = l < TCOLS ? l : 0;
 #pragma unroll
@@ -1053,7 +1084,30 @@ __global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArg
         PA_TICK(3);
         // ================= S6: column c of U ==========================================
         PA_MARK("S6");
-        if (C::HAS_STAB && !(a.ablate & 32u)) {
+        if (UNIT_U && !(a.ablate & 32u)) {
+#pragma unroll
+            for (int r = 0; r < UR; ++r) {
+                const int u = l + r * G;
+                const bool on = (r + 1) * G <= NU || u < NU;          // whole rounds: known at compile time
+                const int uu = on ? u : 0;
+                const int f = uu / CBS, cc = uu - f * CBS;
+                double *zu = S + (on ? C::oZ + NRP + f * FBS + cc * ZS : C::oDUMMY);      // (the sink holds 4 doubles)
+#pragma unroll
+                for (int k = 0; k < FBS; ++k) zu[k] = uval[r][k];
+            }
+            if (l >= CBS && l < MS) {
+                // the NF rows of a face column: zeros (16-byte stores), then the block of its own face on top of them
+                // (LDS writes of a lane land in order)
+                double *zc = S + C::oZ + NRP + c * ZS;
+                static_assert(NF % 2 == 0 && NRP % 2 == 0 && ZS % 2 == 0, "16-byte aligned U columns");
+#pragma unroll
+                for (int r = 0; r < NF; r += 2) *reinterpret_cast<double2 *>(zc + r) = double2{0.0, 0.0};
+                const double msu = -S[C::oSU + fc];
+#pragma unroll
+                for (int k = 0; k < FBS; ++k) zc[fc * FBS + k] = msu * ufc[k];
+            }
+        }
+        if (C::HAS_STAB && !UNIT_U && !(a.ablate & 32u)) {
             if (C::GENERAL_FANCY) {
                 // proj1[:, c] = e_c - M1^-1 (M2 R[:, c])   hho.hpp:184-190
                 double pr[CBS];
