@@ -132,7 +132,11 @@ struct Cfg {
     static constexpr int ND = MS / 2 + 1;                     // rotations of the symmetric update
     // register budget: the k = 3 kernels need > 168 VGPRs to run without spills (measured: 2 waves/SIMD
     // without spills beat 3 with), the others fit 3 waves/SIMD
-    static constexpr int WAVES = PA_WAVES_PER_EU ? PA_WAVES_PER_EU : (MS > 24 ? 2 : 3);
+    // (the dense fancy form carries the mass factor and the dense T_F as well: one step lower, or it spills by the hundred)
+    static constexpr bool DENSE_FANCY = STAB_ == STAB_FANCY && CD_ != FD_ + 1;
+    static constexpr int WAVES = PA_WAVES_PER_EU ? PA_WAVES_PER_EU
+                                 : DENSE_FANCY ? ((MS > 24 || RBS > 10) ? 1 : (MS > 16 || RBS > 6) ? 2 : 3)
+                                               : ((MS > 24 || RBS > 10) ? 2 : 3);
     static constexpr bool HAS_STAB = STAB != STAB_NONE;
     // lc-only path: accumulators -> HBM directly (no LDS image) where the matrix is big enough for the
     // 128-byte runs to pay (measured: -5 % at msize 14, -2 % at 22, -1 % at 31, but +19 % at msize 9)
@@ -538,8 +542,9 @@ __device__ __forceinline__ uint32_t sel4u(uint32_t v0, uint32_t v1, uint32_t v2,
 // -------------------------------------------------------------------------------------
 // SPLIT = false: only lc = data + stab is produced (one accumulator per entry);
 // SPLIT = true:  data and stab are kept apart so that any of lc / data / stab can be written.
+// (the SPLIT variant keeps two accumulator sets and the columns of Y and U in registers: at most 3 waves/SIMD)
 template <class C, bool SPLIT>
-__global__ __launch_bounds__(64, C::WAVES) void hho_local_ops_kernel(LocalOpsArgs a)
+__global__ __launch_bounds__(64, (SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hho_local_ops_kernel(LocalOpsArgs a)
 {
     constexpr int G = C::G, RBS = C::RBS, CBS = C::CBS, FBS = C::FBS, MS = C::MS, NR = C::NR, NF = C::NF;
     constexpr int NQ = C::NQ, NFQ = C::NFQ, NFP = C::NFP, NP = C::NP, RD = C::RD, NPW = C::NPW;
