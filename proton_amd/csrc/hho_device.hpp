@@ -55,6 +55,9 @@
 #ifndef PA_UNIT_U
 #define PA_UNIT_U 1
 #endif
+#ifndef PA_PRE_DENSE
+#define PA_PRE_DENSE 1
+#endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
 #else
@@ -117,9 +120,9 @@ struct Cfg {
     static constexpr int NFP = 4 * NFQ;
     static constexpr bool FANCY = STAB == STAB_FANCY, NAIVE = STAB == STAB_NAIVE;
     static constexpr bool GENERAL_FANCY = FANCY && CD != RD;  // T_F is dense; otherwise T_F = [trace_F | 0]
-    // The per-cell head is taken from the pre-pass (hho_pre.hpp); the dense fancy form also needs the cell mass
-    // matrix and keeps the all-in-one kernel.
-    static constexpr bool USE_PRE = PA_USE_PRE && !GENERAL_FANCY;
+    // The per-cell head is taken from the pre-pass (hho_pre.hpp); for the dense fancy form its record also carries the
+    // rows of the cell mass matrix and the Cholesky factor of its leading block (hho.hpp:173-190).
+    static constexpr bool USE_PRE = PA_USE_PRE && (PA_PRE_DENSE || !GENERAL_FANCY);
     static constexpr int NQB = USE_PRE ? 0 : NQ;              // cell points evaluated by THIS kernel
     static constexpr int NP = NQB + NFP;
     static constexpr int NPW = 2 * RD + 1;                    // powers 0..2 recdeg
@@ -152,8 +155,12 @@ struct Cfg {
     struct Pre {
         static constexpr int NL = (RBS - 1) * RBS / 2;
         static constexpr int oSCAL = (NL + (RBS - 1) + 1) & ~1;
-        static constexpr int NSCAL = 18;
-        static constexpr int NPRE = oSCAL + NSCAL;
+        static constexpr int NSCAL = 18;                      // ([17]: pivot status of the mass factor)
+        // dense fancy form only: rows i < CBS of the cell mass matrix, [j][i]; packed chol(M1), true diagonal; 1/diagonal
+        static constexpr int oMR = oSCAL + NSCAL, NMR = GENERAL_FANCY ? CBS * RBS : 0;
+        static constexpr int oMC = oMR + NMR, NMC = GENERAL_FANCY ? CBS * (CBS + 1) / 2 : 0;
+        static constexpr int oMCR = oMC + NMC;
+        static constexpr int NPRE = (oMCR + (GENERAL_FANCY ? CBS : 0) + 1) & ~1;
         static constexpr int NP2 = NPRE / 2;                  // 16-byte pairs
     };
     static constexpr int PLC = cdiv(Pre::NP2, G);             // pairs of the record per lane
@@ -188,8 +195,8 @@ struct Cfg {
     // starts on a 16-byte boundary
     static constexpr int oST = sizeQ | 1;
     static constexpr int oMA = (oST + LD * RBS + 1) & ~1;     // RBS x RBS  mass (general fancy); chol(M1) in place
-    static constexpr int oFT = oMA + (GENERAL_FANCY ? LD * RBS : 0);     // NF x RBS trace / (|F|/2) (general fancy)
-    static constexpr int oSUo = (oFT + (GENERAL_FANCY ? NF * RBS : 0) + 1) & ~1;   // 4: sqrt(|F| / 2h)
+    static constexpr int oFTo = oMA + (GENERAL_FANCY ? LD * RBS : 0);    // NF x RBS trace / (|F|/2) (general fancy)
+    static constexpr int oSUo = (oFTo + (GENERAL_FANCY ? NF * RBS : 0) + 1) & ~1;   // 4: sqrt(|F| / 2h)
     // region P with the pre-pass: the image of L (NR x LD, row-major, true diagonal; the upper triangle and one
     // more row are zeroed once per kernel and never written again) and the tail of the record as it comes
     // (reciprocals, scalars), shifted so that the scalars start on a 16-byte boundary
@@ -199,7 +206,14 @@ struct Cfg {
     static constexpr int oSU = USE_PRE ? oLIN + (Pre::oSCAL - Pre::NL) : oSUo;
     static constexpr int oLG = USE_PRE ? oLGp : oST + 1 + LD;  // chol(gr_lhs): stiff[1:,1:] in place without the pre-pass
     static constexpr int oDUMMY = oSU + (USE_PRE ? Pre::NSCAL : 4);    // 4: sink of masked-out stores
-    static constexpr int LDS_PER_CELL = (oDUMMY + 4 + 1) & ~1;
+    // dense fancy form on the pre-pass: mass rows, image of chol(M1) (row-major, stride LDM), its reciprocals, trace table
+    static constexpr int LDM = (CBS + 1) & ~1;
+    static constexpr int oMRl = (oDUMMY + 4 + 1) & ~1;
+    static constexpr int oMCl = (oMRl + Pre::NMR + 1) & ~1;
+    static constexpr int oMCRl = oMCl + CBS * LDM;
+    static constexpr int oFTp = (oMCRl + CBS + 1) & ~1;
+    static constexpr int oFT = USE_PRE ? oFTp : oFTo;
+    static constexpr int LDS_PER_CELL = (USE_PRE && GENERAL_FANCY) ? ((oFTp + NF * RBS + 1) & ~1) : ((oDUMMY + 4 + 1) & ~1);
     static constexpr int LDS_DOUBLES = CPW * LDS_PER_CELL;
 };
 
@@ -653,8 +667,16 @@ __global__ __launch_bounds__(64, (SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hh
                 int i = 0;
                 while ((i + 1) * (i + 2) / 2 <= e) ++i;
                 dst = C::oLG + i * LD + (e - i * (i + 1) / 2);
-            } else if (e < PRE::NPRE) {
+            } else if (e < PRE::oMR) {
                 dst = C::oLIN + (e - PRE::NL);
+            } else if (e < PRE::oMC) {
+                dst = C::oMRl + (e - PRE::oMR);
+            } else if (e < PRE::oMCR) {
+                int i = 0;
+                while ((i + 1) * (i + 2) / 2 <= e - PRE::oMC) ++i;
+                dst = C::oMCl + i * C::LDM + (e - PRE::oMC - i * (i + 1) / 2);
+            } else if (e < PRE::oMCR + (C::GENERAL_FANCY ? CBS : 0)) {
+                dst = C::oMCRl + (e - PRE::oMCR);
             }
             pre_dst[t][h] = dst;
         }
@@ -1120,14 +1142,22 @@ __global__ __launch_bounds__(64, (SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hh
                 for (int i = 0; i < CBS; ++i) {
                     double s = 0.0;
 #pragma unroll
-                    for (int k = 0; k < NR; ++k) s += S[C::oMA + i + (1 + k) * LD] * col[k];
+                    for (int k = 0; k < NR; ++k)
+                        s += (C::USE_PRE ? S[C::oMRl + (1 + k) * CBS + i] : S[C::oMA + i + (1 + k) * LD]) * col[k];
                     pr[i] = s;
                 }
-                wave_sync();
-                const int badm = lds_cholesky<CBS, LD, G>(S + C::oMA, l);
+                int badm;
+                if (C::USE_PRE) {          // chol(M1) comes with the record
+                    badm = (int)S[C::oSU + 17];
+                    lds_forward_rd<CBS, C::LDM>(S + C::oMCl, S + C::oMCRl, pr);
+                    lds_backward_rd<CBS, C::LDM>(S + C::oMCl, S + C::oMCRl, pr);
+                } else {
+                    wave_sync();
+                    badm = lds_cholesky<CBS, LD, G>(S + C::oMA, l);
+                    lds_forward<CBS, LD>(S + C::oMA, pr);
+                    lds_backward<CBS, LD>(S + C::oMA, pr);
+                }
                 if (badm && !bad) bad = 100 + badm;
-                lds_forward<CBS, LD>(S + C::oMA, pr);
-                lds_backward<CBS, LD>(S + C::oMA, pr);
 #pragma unroll
                 for (int i = 0; i < CBS; ++i) pr[i] = (i == c ? 1.0 : 0.0) - pr[i];
                 // T_F[:, c] / (|F|/2) = MR1 R[:, c] + MR2 proj1[:, c]   (hho.hpp:222-230; piKF.solve is linear)

@@ -202,7 +202,53 @@ __global__ __launch_bounds__(64) void hho_cell_pre_kernel(PreArgs a)
     // a face runs from its LOWER-id endpoint (basic_geom.hpp:202-203, bases.hpp:260-261): bit f = local face f is
     // traversed against that direction by the cell's CCW vertex order
     const int flags = (idv.x > idv.y ? 1 : 0) | (idv.y > idv.z ? 2 : 0) | (idv.z > idv.w ? 4 : 0) | (idv.w > idv.x ? 8 : 0);
-    put(PL::oSCAL + 16, double2{(double)flags, 0.0});
+    // ---- dense fancy form: rows i < CBS of the cell mass matrix (M2 of hho.hpp:185 is its columns 1..) and the Cholesky
+    // factor of M1 = mass[:cbs, :cbs] (hho.hpp:184,188), both from the same moments
+    int badm = 0;
+    if (C::GENERAL_FANCY) {
+        constexpr int CBS = C::CBS, CD = C::CD, NT = C::GENERAL_FANCY ? PL::NPRE - PL::oMR : 2;      // (sizes > 0 in the instances without it)
+        double tail[NT];
+#pragma unroll
+        for (int e = 0; e < NT; ++e) tail[e] = 0.0;
+        double MC[CBS * (CBS + 1) / 2], mrd[CBS];
+#pragma unroll
+        for (int kj = 0; kj <= RD; ++kj)
+#pragma unroll
+            for (int rj = 0; rj <= kj; ++rj)
+#pragma unroll
+                for (int ki = 0; ki <= CD; ++ki)
+#pragma unroll
+                    for (int ri = 0; ri <= ki; ++ri) {
+                        const int mi = ki * (ki + 1) / 2 + ri, mj = kj * (kj + 1) / 2 + rj;
+                        const int pb = ri + rj, kk = ki + kj;                   // phi_i phi_j = bx^(kk - pb) by^pb
+                        const double v = mom[kk * (kk + 1) / 2 + pb];
+                        tail[mj * CBS + mi] = v;
+                        if (mj <= mi) MC[mi * (mi + 1) / 2 + (mj < CBS ? mj : 0)] = v;
+                    }
+#pragma unroll
+        for (int r = 0; r < CBS; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                double s = MC[r * (r + 1) / 2 + c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) s = __builtin_fma(-MC[r * (r + 1) / 2 + k], MC[c * (c + 1) / 2 + k], s);
+                if (c < r) {
+                    MC[r * (r + 1) / 2 + c] = s * mrd[c];
+                } else {
+                    if (!(s > 0.0) && !badm) badm = r + 1;
+                    mrd[r] = fast_rsqrt<2>(s);
+                    MC[r * (r + 1) / 2 + r] = s * mrd[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < PL::NMC; ++e) tail[PL::NMR + e] = MC[e];
+#pragma unroll
+        for (int e = 0; e < CBS; ++e) tail[PL::NMR + PL::NMC + e] = mrd[e];
+#pragma unroll
+        for (int e = 0; e + 1 < NT; e += 2) put(PL::oMR + e, double2{tail[e], tail[e + 1]});
+    }
+    put(PL::oSCAL + 16, double2{(double)flags, (double)badm});
 }
 
 }  // namespace pa
