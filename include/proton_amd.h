@@ -120,7 +120,10 @@ int pa_mesh_counts(pa_context *ctx, size_t *npoints, size_t *ncells);
  *   d_oper (rbs-1) x msize, d_data/d_stab/d_lc msize x msize, d_info one int32
  *   (0, or 1+index of the first non-positive Cholesky pivot: 100+ for the cell-mass
  *   factorization of the fancy stabilization).
- * Asynchronous on the context's stream. */
+ * Asynchronous on the context's stream.  Two kernels per call: a one-thread-per-cell pre-pass and the
+ * cooperative kernel, which meet in a record buffer the CONTEXT owns (grown on demand, at most 4 GiB --
+ * PA_PRE_BYTES overrides -- larger ranges run in equal pieces; freed by pa_context_destroy).  Calls on one
+ * context are serialized by its stream, so the buffer needs no locking; use one context per stream. */
 int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind,
                        size_t first, size_t n,
                        double *d_oper, double *d_data, double *d_stab, double *d_lc,

@@ -669,12 +669,15 @@ int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int st
     // piece into the context's record buffer, then the cooperative kernel over the same cells (same stream).
     size_t piece = n;
     if (e->launch_pre) {
-        size_t cap_bytes = (size_t)1 << 30;                               // 1 GiB of records: 2 M cells at k = 2
+        size_t cap_bytes = (size_t)4 << 30;                               // 4 GiB of records: 7 M cells at k = 2, 3.9 M at k = 3
         if (const char *env = std::getenv("PA_PRE_BYTES")) cap_bytes = (size_t)std::strtoull(env, nullptr, 0);
         const size_t per_cell = (size_t)e->pre_doubles * sizeof(double);
-        size_t max_cells = cap_bytes / per_cell;
+        size_t max_cells = (cap_bytes / per_cell) & ~(size_t)4095;
         if (max_cells < 4096) max_cells = 4096;
-        if (piece > max_cells) piece = max_cells & ~(size_t)4095;
+        if (piece > max_cells) {                                          // equal pieces, whole multiples of 4096 cells
+            const size_t npieces = (n + max_cells - 1) / max_cells;
+            piece = (((n + npieces - 1) / npieces) + 4095) & ~(size_t)4095;
+        }
         const size_t need = ((piece + 7) / 8) * 8 * (size_t)e->pre_doubles;      // whole tiles of 8 records
         if (ctx->pre_capacity < need) {
             if (ctx->d_pre) { PA_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_pre); ctx->d_pre = nullptr; ctx->pre_capacity = 0; }
