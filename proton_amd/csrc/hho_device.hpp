@@ -9,10 +9,13 @@
 //                                 src/core/core_bits/quadratures.hpp:78-158, 238-432
 //   barycenter/diameter/measure/normals  src/core/core_bits/basic_geom.hpp:247-372
 //
-// HOW is not the reference's.  G lanes of a 64-wide wavefront cooperate on one cell:
+// HOW is not the reference's.  The path is two kernels: the per-cell head -- geometry, cell quadrature, moments,
+// stiffness, Cholesky of gr_lhs (and the mass rows / factor of the dense fancy form) -- runs one THREAD per cell
+// (hho_pre.hpp) and hands a small record per cell to the kernel of this file, in which G lanes of a 64-wide
+// wavefront cooperate on one cell (a -DPA_USE_PRE=0 build keeps the head in this kernel: stages S0-S4 below):
 //   * the cell basis is a set of scaled monomials, so every cell integral of phi_i phi_j or
 //     grad phi_i . grad phi_j is a *moment*  sum_q w_q bx_q^p by_q^r  of the same quadrature
-//     rule: P2(2 recdeg) moments are accumulated (one lane each) and the stiffness / mass
+//     rule: P2(2 recdeg) moments are accumulated and the stiffness / mass
 //     matrices are gathered from them -- term by term the same sums the reference forms;
 //   * the face basis evaluated at the face Gauss points is t_q^k exactly, so every face mass
 //     matrix is (|F|/2) M^ with one constant factorization shared by all faces of all cells;
@@ -23,9 +26,12 @@
 //     B_F = M_F^-1 T_F - E_F is the reference's proj2 + proj3 (hho.hpp:222-231); T_F = [trace_F | 0]
 //     for the naive stabilization and for the fancy one when celdeg == recdeg (then
 //     pi_T^k p_T^k v == p_T^k v and hho.hpp:184-190 cancels);
-//   * lc = Z^T Z with Z = [Y; U]: one symmetric rank update, each lane forming the entries
-//     (c, c+d mod msize), d = 0..msize/2, mirrored through an LDS image of the matrix and
-//     streamed to HBM with coalesced 16-byte stores;
+//   * lc = Z^T Z with Z = [Y; U]: one symmetric rank update -- on v_mfma_f64_16x16x4_f64 when only lc is
+//     asked for (one LDS read per lane feeds 16 FMAs), accumulators to HBM directly or through an LDS image;
+//     each lane forming the entries (c, c+d mod msize), d = 0..msize/2, with vector FMAs when data and stab
+//     are wanted apart;
+//   * the block's one wavefront synchronises on its LDS data with wave_sync() (no wait for outstanding
+//     stores), and the next cell's record is in flight while the current cell is processed;
 //   * reciprocals and square roots are v_rcp/v_rsq seeds refined by Newton steps (<= 1 ulp).
 #pragma once
 
