@@ -64,6 +64,9 @@
 #ifndef PA_PRE_DENSE
 #define PA_PRE_DENSE 1
 #endif
+#ifndef PA_GRC_MFMA
+#define PA_GRC_MFMA 1
+#endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
 #else
@@ -944,7 +947,32 @@ __global__ __launch_bounds__(64, (SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hh
         // the GRC scratch (on the dead quadrature tables) and the column owner reloads them after
         // the barrier below.
         constexpr int SPC = C::SPC, RPP = C::RPP;
+        // With the pre-pass the cell columns start from zero: -F = -DN^T PHF (NR x CBS, inner dimension the NFP face
+        // points) is one 16 x 16 tile of the matrix pipe per cell, NFP/4 instructions, each lane reading ONE element of
+        // either table per step (the vector form reads 4 per 3 FMAs, and the LDS pipeline is the busiest of the kernel).
+        // (measured: -5 % at k = 3; nothing at k = 2, where it costs the 4th wave its last registers)
+        constexpr bool GRC_MFMA = C::USE_PRE && SPC > 1 && PA_GRC_MFMA && NR >= 12 && NR <= 16 && CBS <= 16;
         if (a.ablate & 4u) {
+        } else if (GRC_MFMA) {
+            typedef double v4d_ __attribute__((ext_vector_type(4)));
+            const int kk_ = lane >> 4, jj_ = lane & 15;
+#pragma unroll
+            for (int gi = 0; gi < C::CPW; ++gi) {
+                double *Sg = smem + gi * C::LDS_PER_CELL;
+                v4d_ f = v4d_{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < NFP / 4; ++ks) {
+                    const int pf = 4 * ks + kk_;
+                    const double av = Sg[C::oDN + pf * NRP + (jj_ < NR ? jj_ : 0)];
+                    const double bv = Sg[C::oPHF + pf * RBS + (jj_ < CBS ? jj_ : 0)];
+                    f = __builtin_amdgcn_mfma_f64_16x16x4f64(jj_ < NR ? av : 0.0, jj_ < CBS ? bv : 0.0, f, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = kk_ + 4 * r;
+                    if (4 * r < NR && (4 * r + 3 < NR || row < NR) && jj_ < CBS) Sg[C::oGRC + jj_ * NRP + row] = -f[r];
+                }
+            }
         } else if (SPC > 1) {
             if (l < SPC * CBS) {
                 const int part = l / CBS, cc = l % CBS, r0 = part * RPP;
