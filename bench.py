@@ -208,6 +208,7 @@ def main():
         if world > 1:
             raise SystemExit("the cut workload is single-GPU in this round")
         asm.cut_preprocess(N, refsteps=4)                    # host preprocessing: outside the timed region
+        asm.ctx.set_cut_overlap(not os.environ.get("PA_NO_CUT_OVERLAP"))
     elif w.get("perturb"):
         if world > 1:
             raise SystemExit("the general-quadrilateral workload is single-GPU in this round")
@@ -236,6 +237,10 @@ def main():
 
     def step(i=None):
         if not exchange:
+            if cut and asm.ncut:
+                # the cut cells first, on the context's side stream: they overlap the uncut cells' kernels below
+                asm.ctx.cut_local_ops(w["fd"], asm.level_set, pa.capi.LOC_NEGATIVE, w["fn"], 2, None, None, None,
+                                      cut_lc.data_ptr(), cut_rhs.data_ptr(), None)
             if i is not None:
                 k_start[i][0].record()
             asm.local_ops(w["cd"], w["fd"], quad, stab, want=(), out=out)
@@ -243,8 +248,6 @@ def main():
                 k_stop[i][0].record()
             asm.cell_rhs(w["cd"], w["fn"], quad, dinc=w["dinc"], out=rhs)
             if cut and asm.ncut:
-                asm.ctx.cut_local_ops(w["fd"], asm.level_set, pa.capi.LOC_NEGATIVE, w["fn"], 2, None, None, None,
-                                      cut_lc.data_ptr(), cut_rhs.data_ptr(), None)
                 asm.ctx.cut_merge(w["fd"], pa.capi.LOC_NEGATIVE, cut_lc.data_ptr(), cut_rhs.data_ptr(), lc.data_ptr(), rhs.data_ptr())
             return
         # N > 1: piece by piece; the collective of piece k overlaps the kernels of piece k + 1

@@ -83,6 +83,12 @@ int pa_sizes_for(pa_degree_info di, int quad_kind, pa_sizes *out);
 int pa_context_create(int device, void *stream, int own_stream, pa_context **out);
 int pa_context_destroy(pa_context *ctx);
 int pa_context_synchronize(pa_context *ctx);
+/* on != 0: pa_cut_local_ops_batch / pa_cut_rhs_sampled_batch run on a side stream of the context, next to whatever
+ * is enqueued on its main stream AFTER them -- call them before pa_local_ops_batch so that the few cut cells
+ * (one wavefront each, a long serial chain) overlap the uncut cells' kernels (cuthho_square.cpp:883-900 handles
+ * both kinds in one loop).  Their outputs are ordered only before pa_cut_merge and pa_context_synchronize.
+ * Off by default: everything on the one stream, in call order. */
+int pa_context_set_cut_overlap(pa_context *ctx, int on);
 const char *pa_last_error(pa_context *ctx);      /* text of the last HIP failure, "" if none  */
 int pa_abi_version(void);
 

@@ -231,18 +231,28 @@ class BatchAssembler:
                                _ptr(out.get("stab")), _ptr(out.get("lc")), _ptr(out.get("rhs")), _ptr(out.get("info")))
         return out
 
-    def fictdom_local_ops(self, fd, where=capi.LOC_NEGATIVE, rhs_fn=capi.FN_SIN_SIN_RHS, bcs_fn=capi.FN_SIN_SIN_SOL):
+    def fictdom_local_ops(self, fd, where=capi.LOC_NEGATIVE, rhs_fn=capi.FN_SIN_SIN_RHS, bcs_fn=capi.FN_SIN_SIN_SOL,
+                          overlap=False):
         """The whole loop body of cuthho_square.cpp:883-900 for every cell: uncut cells through the
         fan-quadrature / naive-stabilization kernel, cut cells through the cut kernel, merged.
-        -> (lc [n, ms, ms], rhs [n, cbs]) device tensors."""
+        overlap: the cut cells' kernel first, on the context's side stream (pa_context_set_cut_overlap), next to
+        the uncut cells' kernels.  -> (lc [n, ms, ms], rhs [n, cbs]) device tensors."""
         cd = fd + 1
+        cut = None
+        if overlap:
+            self.ctx.set_cut_overlap(True)
+            if self.ncut:
+                cut = self.cut_local_ops(fd, where, rhs_fn, bcs_fn, want=("lc", "rhs"))
         out = self.local_ops(cd, fd, capi.QUAD_FAN, capi.STAB_NAIVE, want=("lc",))
         rhs = self.cell_rhs(cd, rhs_fn, capi.QUAD_FAN)
         if self.ncut:
-            cut = self.cut_local_ops(fd, where, rhs_fn, bcs_fn, want=("lc", "rhs"))
+            if cut is None:
+                cut = self.cut_local_ops(fd, where, rhs_fn, bcs_fn, want=("lc", "rhs"))
             self.ctx.cut_merge(fd, where, cut["lc"].data_ptr(), cut["rhs"].data_ptr(), out["lc"].data_ptr(), rhs.data_ptr())
         else:
             self.ctx.cut_merge(fd, where, None, None, None, rhs.data_ptr())
+        if overlap:
+            self.ctx.set_cut_overlap(False)
         return out["lc"], rhs
 
     # ---- cutHHO two-sided interface problem (cuthho_square -i) ------------------------------

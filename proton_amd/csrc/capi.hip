@@ -102,6 +102,10 @@ struct pa_context {
     // records of the per-cell pre-pass (hho_pre.hpp), grown on demand, reused by every local-operator call
     double *d_pre = nullptr;
     size_t pre_capacity = 0;                  // doubles
+    // pa_context_set_cut_overlap: the cut-cell kernel runs on a side stream next to the uncut cells' kernels
+    hipStream_t side = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    bool cut_overlap = false, side_pending = false;
     std::string last_error;
 };
 
@@ -250,9 +254,13 @@ int pa_context_destroy(pa_context *ctx)
     if (!ctx) return PA_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     release_mesh(ctx);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_pre) (void)hipFree(ctx->d_pre);
+    if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
+    if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PA_OK;
@@ -261,7 +269,25 @@ int pa_context_destroy(pa_context *ctx)
 int pa_context_synchronize(pa_context *ctx)
 {
     if (!ctx) return PA_ERR_INVALID_ARG;
+    if (ctx->side) { PA_HIP(ctx, hipStreamSynchronize(ctx->side)); ctx->side_pending = false; }
     PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PA_OK;
+}
+
+int pa_context_set_cut_overlap(pa_context *ctx, int on)
+{
+    if (!ctx) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (on && !ctx->side) {
+        PA_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        PA_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+        PA_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
+    }
+    if (!on && ctx->side_pending) {                      // join what is still out on the side stream
+        PA_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+        ctx->side_pending = false;
+    }
+    ctx->cut_overlap = on != 0;
     return PA_OK;
 }
 
@@ -1157,12 +1183,26 @@ static int cut_local_ops(pa_context *ctx, int face_deg, const pa_level_set *ls, 
         a.eta = 5.0;                                                             // cell_eta, cuthho_square.cpp:301-306
         a.oper = d_oper; a.data = d_data; a.stab = d_stab; a.lc = d_lc; a.rhs = d_rhs; a.info = d_info;
         const int grid = (int)(ncut < (size_t)ctx->num_cus * 4 ? ncut : (size_t)ctx->num_cus * 4);
-        switch (face_deg) {
-        case 0: hipLaunchKernelGGL((pa::cut_local_ops_kernel<0>), dim3(grid), dim3(64), 0, ctx->stream, a); break;
-        case 1: hipLaunchKernelGGL((pa::cut_local_ops_kernel<1>), dim3(grid), dim3(64), 0, ctx->stream, a); break;
-        default: hipLaunchKernelGGL((pa::cut_local_ops_kernel<2>), dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        // With pa_context_set_cut_overlap the kernel goes to the side stream, after everything enqueued on the
+        // context's stream so far (the previous merge reads the buffers it writes); pa_cut_merge joins it.
+        hipStream_t st_ = ctx->stream;
+        if (ctx->cut_overlap && ctx->side) {
+            e = hipEventRecord(ctx->ev_main, ctx->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->side, ctx->ev_main, 0);
+            st_ = ctx->side;
         }
-        e = hipGetLastError();
+        if (e == hipSuccess) {
+            switch (face_deg) {
+            case 0: hipLaunchKernelGGL((pa::cut_local_ops_kernel<0>), dim3(grid), dim3(64), 0, st_, a); break;
+            case 1: hipLaunchKernelGGL((pa::cut_local_ops_kernel<1>), dim3(grid), dim3(64), 0, st_, a); break;
+            default: hipLaunchKernelGGL((pa::cut_local_ops_kernel<2>), dim3(grid), dim3(64), 0, st_, a); break;
+            }
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess && st_ != ctx->stream) {
+            e = hipEventRecord(ctx->ev_side, ctx->side);
+            ctx->side_pending = true;
+        }
     }
     if (e != hipSuccess) { ctx->last_error = std::string("pa_cut_local_ops_batch: ") + hipGetErrorString(e); return PA_ERR_HIP; }
     return PA_OK;
@@ -1176,6 +1216,10 @@ int pa_cut_merge(pa_context *ctx, int face_deg, int where, const double *d_cut_l
     const int cbs = pa::P2(face_deg + 1), ms = cbs + 4 * (face_deg + 1);
     const uint32_t nc = (uint32_t)ctx->cut->ncells();
     const int grid = (int)(nc < (uint32_t)ctx->num_cus * 16 ? nc : (uint32_t)ctx->num_cus * 16);
+    if (ctx->side_pending) {                              // the cut cells' kernel ran on the side stream
+        PA_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+        ctx->side_pending = false;
+    }
     hipLaunchKernelGGL(pa::cut_merge_kernel, dim3(grid), dim3(64), 0, ctx->stream, nc, ctx->d_cell_loc, ctx->d_cut_index, where,
                        ms * ms, cbs, d_cut_lc, d_cut_rhs, d_lc, d_rhs);
     PA_HIP(ctx, hipGetLastError());

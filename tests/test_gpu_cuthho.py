@@ -94,6 +94,22 @@ def test_cut_rhs_with_caller_sampled_functions(asm, N, k, where):
     assert np.all(np.add.reduceat(xyw0[:, 2], off0[:-1].astype(np.int64)) > 0)
 
 
+@pytest.mark.parametrize("N,k", [(40, 1), (64, 2)])
+def test_cut_kernel_on_the_side_stream_gives_the_same_matrices(asm, N, k):
+    """pa_context_set_cut_overlap: the cut cells' kernel on the context's side stream, next to the uncut cells'
+    kernels, joined by pa_cut_merge -- bit for bit what the one-stream sequence produces, several times in a row
+    (the second pass waits for the first merge before it overwrites the cut buffers)."""
+    import torch
+    asm.cut_preprocess(N, refsteps=4)
+    lc0, rhs0 = asm.fictdom_local_ops(k)
+    asm.synchronize()
+    lc0, rhs0 = lc0.clone(), rhs0.clone()
+    for _ in range(3):
+        lc1, rhs1 = asm.fictdom_local_ops(k, overlap=True)
+        asm.synchronize()
+        assert torch.equal(lc0, lc1) and torch.equal(rhs0, rhs1)
+
+
 def test_cut_error_codes(asm):
     import ctypes as C
     import proton_amd as pa
