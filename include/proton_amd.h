@@ -87,7 +87,8 @@ int pa_context_synchronize(pa_context *ctx);
  * is enqueued on its main stream AFTER them -- call them before pa_local_ops_batch so that the few cut cells
  * (one wavefront each, a long serial chain) overlap the uncut cells' kernels (cuthho_square.cpp:883-900 handles
  * both kinds in one loop).  Their outputs are ordered only before pa_cut_merge and pa_context_synchronize.
- * Off by default: everything on the one stream, in call order. */
+ * Off by default: everything on the one stream, in call order.  (Pays only when the main stream's kernels leave
+ * room: next to the persistent local-operator grid of a 512^2 mesh it measured 8 % slower than the plain sequence.) */
 int pa_context_set_cut_overlap(pa_context *ctx, int on);
 const char *pa_last_error(pa_context *ctx);      /* text of the last HIP failure, "" if none  */
 int pa_abi_version(void);

@@ -1182,7 +1182,11 @@ static int cut_local_ops(pa_context *ctx, int face_deg, const pa_level_set *ls, 
         a.rhs_fn = rhs_fn; a.bcs_fn = bcs_fn; a.rhs_vals = d_rhs_vals; a.bcs_vals = d_bcs_vals;
         a.eta = 5.0;                                                             // cell_eta, cuthho_square.cpp:301-306
         a.oper = d_oper; a.data = d_data; a.stab = d_stab; a.lc = d_lc; a.rhs = d_rhs; a.info = d_info;
-        const int grid = (int)(ncut < (size_t)ctx->num_cus * 4 ? ncut : (size_t)ctx->num_cus * 4);
+        // one wavefront per cut cell and a long serial chain per cell: as many blocks as the chip holds (2 per SIMD),
+        // so that a few thousand cut cells take ONE cell's latency, not two or three
+        size_t cap_blocks = (size_t)ctx->num_cus * 8;
+        if (const char *env = std::getenv("PA_CUT_BLOCKS_PER_CU")) { const int v = std::atoi(env); if (v > 0) cap_blocks = (size_t)ctx->num_cus * v; }
+        const int grid = (int)(ncut < cap_blocks ? ncut : cap_blocks);
         // With pa_context_set_cut_overlap the kernel goes to the side stream, after everything enqueued on the
         // context's stream so far (the previous merge reads the buffers it writes); pa_cut_merge joins it.
         hipStream_t st_ = ctx->stream;
