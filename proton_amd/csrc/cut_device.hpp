@@ -42,6 +42,8 @@ __device__ __forceinline__ double ipow(double x, int n)
 }
 
 template <int FD>
+// (a block is one wavefront: wave_sync() orders its LDS traffic without the wait for outstanding loads / stores that
+// __syncthreads() adds -- the quadrature lists of the next chunk stay in flight)
 __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
 {
     constexpr int RD = FD + 1, RBS = P2(RD), CBS = RBS, FBS = FD + 1, NF = 4 * FBS, MS = CBS + NF;
@@ -124,18 +126,18 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                 }
                 S[oTPHI + l * ROWW + 2 * NPW] = a.rhs == nullptr ? 0.0 : (a.rhs_fn == FN_SAMPLED ? a.rhs_vals[q] : builtin_fn(a.rhs_fn, x, y));
             }
-            __syncthreads();
+            wave_sync();
             const int nq = (int)((c1 - base) < (uint32_t)CH ? (c1 - base) : (uint32_t)CH);
             if (l < NMOM)
                 for (int t = 0; t < nq; ++t) mom_acc += S[oTPHI + t * ROWW + mp] * S[oTPHI + t * ROWW + NPW + mr];
             if (l < CBS)
                 for (int t = 0; t < nq; ++t)
                     rhs_acc += (S[oTPHI + t * ROWW + rp] * S[oTPHI + t * ROWW + NPW + rr]) * S[oTPHI + t * ROWW + 2 * NPW];
-            __syncthreads();
+            wave_sync();
         }
         static_assert(NMOM <= 64, "one lane per moment");
         if (l < NMOM) S[oMOM + l] = mom_acc;
-        __syncthreads();
+        wave_sync();
         for (int e = l; e < RBS * RBS; e += 64) {
             int ai, bi, aj, bj;
             mono_exps(e % RBS, ai, bi);
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
             if (bi * bj) v += (double)(bi * bj) * S[oMOM + mono_index(ai + aj, bi + bj - 2)];
             S[oST + (e % RBS) + (e / RBS) * LD] = ih * ih * v;
         }
-        __syncthreads();
+        wave_sync();
 
         // ---- B: Nitsche terms on the interface (cuthho_square.cpp:347-360), chunks of 64 points
         const uint32_t i0 = a.il_off[cc], i1 = a.il_off[cc + 1];
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                 }
                 S[oTW + l] = a.il_xyw[3 * q + 2];
             } else S[oTW + l] = 0.0;
-            __syncthreads();
+            wave_sync();
             const int nq = (int)((i1 - base) < (uint32_t)CH ? (i1 - base) : (uint32_t)CH);
             for (int e = l; e < RBS * RBS; e += 64) {
                 const int i = e % RBS, j = e / RBS;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                 }
                 S[oST + i + j * LD] += s;
             }
-            __syncthreads();
+            wave_sync();
         }
 
         // ---- C: gr_lhs = stiff, gr_rhs (cuthho_square.cpp:362-383); face points of the `where` part
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                 }
                 for (int k = 0; k < FBS; ++k) S[oFB + l * FBS + k] = ipow(ep, k);
             }
-            __syncthreads();
+            wave_sync();
             for (int e = l; e < RBS * MS; e += 64) {
                 const int i = e % RBS, j = e / RBS;
                 double s;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                 S[oGR + i + j * RBS] = s;
             }
             for (int e = l; e < RBS * LD; e += 64) S[oLL + e] = S[oST + e];
-            __syncthreads();
+            wave_sync();
         }
 
         // ---- D: oper = llt(gr_lhs).solve(gr_rhs) (cuthho_square.cpp:385), full rbs x rbs system
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                 for (int k = 0; k < RBS; ++k) S[oOP + k + c * RBS] = x[k];
             }
         }
-        __syncthreads();
+        wave_sync();
         if (a.oper != nullptr)
             for (int e = l; e < RBS * MS; e += 64) a.oper[(size_t)cc * (RBS * MS) + e] = S[oOP + e];
 
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
             for (int k = 0; k < RBS; ++k) s += S[oGR + k + i * RBS] * S[oOP + k + j * RBS];
             S[oDATA + e] = s;
         }
-        __syncthreads();
+        wave_sync();
 
         // ---- F: cut stabilization (cuthho_square.cpp:566-621): faces without points are skipped
         {
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                 for (int k = 0; k < FBS; ++k) S[oFB + l * FBS + k] = ipow(ep, k);
                 S[oTW + l] = w;
             }
-            __syncthreads();
+            wave_sync();
             for (int e = l; e < 4 * FBS * FBS; e += 64) {              // mass_F  (:608)
                 const int f = e / (FBS * FBS), k = e % FBS, k2 = (e / FBS) % FBS;
                 double s = 0.0;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                 }
                 S[oTR + fk + i * NF] = s;
             }
-            __syncthreads();
+            wave_sync();
             if (l < CBS) {                                             // mass.llt().solve(trace), column l (:615)
 #pragma unroll 1
                 for (int f = 0; f < 4; ++f) {
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                     for (int i = 0; i < FBS; ++i) S[oPT + (f * FBS + i) + l * NF] = x[i];
                 }
             }
-            __syncthreads();
+            wave_sync();
             // data += oper_F^T mass_F oper_F / hT, oper_F = [ M^-1 trace | -I_F ]  (:599,:615-617); outputs
             const size_t off = (size_t)cc * (MS * MS);
 #pragma unroll 1
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                     S[oTPHI + 5 * l + 3] = nx;
                     S[oTPHI + 5 * l + 4] = ny;
                 }
-                __syncthreads();
+                wave_sync();
                 const int nq = (int)((r1 - base) < (uint32_t)CH ? (r1 - base) : (uint32_t)CH);
                 if (l < CBS)
                     for (int t = 0; t < nq; ++t) {
@@ -376,11 +378,11 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                         grad_m(bx, by, l, gx, gy);
                         s += S[oTPHI + 5 * t + 2] * (phi_m(bx, by, l) * eta_h - (gx * S[oTPHI + 5 * t + 3] + gy * S[oTPHI + 5 * t + 4]));
                     }
-                __syncthreads();
+                wave_sync();
             }
             if (l < CBS) a.rhs[(size_t)cc * CBS + l] = s;
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 

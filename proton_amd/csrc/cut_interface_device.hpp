@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
         };
 
         for (int e = l; e < LD2 * N2; e += 64) S[oST + e] = 0.0;
-        __syncthreads();
+        wave_sync();
 
         // ---- A: per side, cell moments -> kappa_s * stiffness block (:419-432) and the volume
         // right-hand side of that side (cuthho_utils.hpp:75-81; degree == recdeg: the same points)
@@ -117,18 +117,18 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
                     }
                     S[oTPHI + l * ROWW + 2 * NPW] = a.rhs != nullptr ? builtin_fn(a.rhs_fn, x, y) : 0.0;
                 }
-                __syncthreads();
+                wave_sync();
                 const int nq = (int)((c1 - base) < (uint32_t)CH ? (c1 - base) : (uint32_t)CH);
                 if (l < NMOM)
                     for (int t = 0; t < nq; ++t) mom_acc += S[oTPHI + t * ROWW + mp] * S[oTPHI + t * ROWW + NPW + mr];
                 if (l < CBS)
                     for (int t = 0; t < nq; ++t)
                         rhs_acc += (S[oTPHI + t * ROWW + rp] * S[oTPHI + t * ROWW + NPW + rr]) * S[oTPHI + t * ROWW + 2 * NPW];
-                __syncthreads();
+                wave_sync();
             }
             if (l < NMOM) S[oMOM + l] = mom_acc;
             if (a.rhs != nullptr && l < CBS) a.rhs[(size_t)cc * (2 * CBS) + side * CBS + l] = rhs_acc;      // :1710-1711
-            __syncthreads();
+            wave_sync();
             const double ks = a.kappa[side] * ih * ih;
             for (int e = l; e < RBS * RBS; e += 64) {
                 int ai, bi, aj, bj;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
                 if (bi * bj) v += (double)(bi * bj) * S[oMOM + mono_index(ai + aj, bi + bj - 2)];
                 S[oST + (side * RBS + e % RBS) + (side * RBS + e / RBS) * LD2] = ks * v;
             }
-            __syncthreads();
+            wave_sync();
         }
 
         // ---- B: interface terms (:437-459) with a = k1 w phi (dphi.n)^T, b = a^T, c = k1 w eta/hT phi phi^T:
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
                     }
                     S[oTW + l] = a.kappa[0] * a.il_xyw[3 * q + 2];
                 } else S[oTW + l] = 0.0;
-                __syncthreads();
+                wave_sync();
                 const int nq = (int)((i1 - base) < (uint32_t)CH ? (i1 - base) : (uint32_t)CH);
 #pragma unroll
                 for (int u = 0; u < (RBS * RBS + 63) / 64; ++u) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
                         }
                     }
                 }
-                __syncthreads();
+                wave_sync();
             }
 #pragma unroll
             for (int u = 0; u < (RBS * RBS + 63) / 64; ++u) {
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
                     S[oST + (RBS + i) + (RBS + j) * LD2] += acc_c[u];
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
 
         // ---- C: gr_rhs (:461-495).  Columns: [cell- | cell+ | faces- | faces+]
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
             const int i = e % N2, j = e / N2;
             S[oGR + e] = j < CBS ? S[oST + i + j * LD2] : (j < 2 * CBS ? S[oST + i + (RBS + j - CBS) * LD2] : 0.0);
         }
-        __syncthreads();
+        wave_sync();
 #pragma unroll 1
         for (int side = 0; side < 2; ++side) {
             if (l < NFPT) {
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
                 }
                 for (int k = 0; k < FBS; ++k) S[oFB + l * FBS + k] = ipow(ep, k);
             }
-            __syncthreads();
+            wave_sync();
             for (int e = l; e < RBS * MS; e += 64) {
                 const int i = e % RBS, j = e / RBS;
                 if (j < CBS) {                                              // :479, :491
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
                     S[oGR + (side * RBS + i) + (2 * CBS + side * NF + f * FBS + k) * N2] = s;
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
 
         // ---- D: oper = gr_lhs^+ gr_rhs with the first unknown pinned (see the header comment)
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
             const int i = e / LDR, k = e % LDR;
             S[oLL + e] = k < NR ? S[oST + (i + 1) + (k + 1) * LD2] : 0.0;
         }
-        __syncthreads();
+        wave_sync();
         const int bad = lds_cholesky<NR, LDR, 64, 2>(S + oLL, l);
         {
             double x[NR];
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
                 for (int k = 0; k < NR; ++k) S[oOP + (k + 1) + c * N2] = x[k];
             }
         }
-        __syncthreads();
+        wave_sync();
         if (a.oper != nullptr)
             for (int e = l; e < N2 * M2; e += 64) a.oper[(size_t)cc * (N2 * M2) + e] = S[oOP + e];
 
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
             }
         }
         if (a.info != nullptr && l == 0) a.info[cc] = bad;
-        __syncthreads();
+        wave_sync();
     }
 }
 
