@@ -10,6 +10,9 @@
 
 #include "hho_device.hpp"
 
+#ifndef PA_SC_FENCE_MIN
+#define PA_SC_FENCE_MIN 11
+#endif
 namespace pa {
 
 enum { FN_SAMPLED = 0, FN_SIN_SIN_RHS = 1, FN_SIN_SIN_SOL = 2, FN_OBSTACLE_RHS = 3, FN_OBSTACLE_SOL = 4, FN_ONE = 5 };
@@ -298,8 +301,22 @@ __global__ __launch_bounds__(64) void static_condensation_kernel(size_t n, const
 #pragma unroll
         for (int i = 0; i < CBS; ++i)
             x[i] = (c == 0) ? (rhs != nullptr ? rhs[cell * CBS + i] : 0.0) : -A[i + (CBS + c - 1) * MS];
-        lds_forward<CBS, LDC>(LT, x);
-        lds_backward<CBS, LDC>(LT, x);
+        // row by row, with a scheduling fence between rows when the system is large: left alone the compiler issues the
+        // LDS reads of all rows up front (336 VGPRs at cbs = 15: one wave per SIMD)
+#pragma unroll
+        for (int i = 0; i < CBS; ++i) {
+            if (CBS >= PA_SC_FENCE_MIN) __builtin_amdgcn_sched_barrier(0);
+            const double s = i == 0 ? x[0] : lds_dotsub_n(x[i], LT + i * LDC, x, i);
+            x[i] = s * LT[i * LDC + i];
+        }
+#pragma unroll
+        for (int i = CBS - 1; i >= 0; --i) {
+            if (CBS >= PA_SC_FENCE_MIN) __builtin_amdgcn_sched_barrier(0);
+            double s = x[i];
+#pragma unroll
+            for (int k = i + 1; k < CBS; ++k) s -= LT[k * LDC + i] * x[k];
+            x[i] = s * LT[i * LDC + i];
+        }
         if (recout != nullptr && valid && l <= NF) {
 #pragma unroll
             for (int i = 0; i < CBS; ++i) recout[cell * (size_t)(CBS * (NF + 1)) + (size_t)c * CBS + i] = x[i];
