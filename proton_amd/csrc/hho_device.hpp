@@ -67,6 +67,9 @@
 #ifndef PA_GRC_MFMA
 #define PA_GRC_MFMA 1
 #endif
+#ifndef PA_XCD_MAP
+#define PA_XCD_MAP 1
+#endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
 #else
@@ -697,7 +700,7 @@ __global__ __launch_bounds__(64, (SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hh
     double2 rec[C::PLC];
     // Blocks b and b + 8 share an XCD (round-robin dispatch; a speed assumption only): give the blocks of an XCD
     // consecutive cells, so that the 8 cells of a record tile, and the lines of lc they share, meet in one L2.
-    const size_t lblock = (gridDim.x % 8 == 0) ? (size_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (size_t)blockIdx.x;
+    const size_t lblock = (PA_XCD_MAP && gridDim.x % 8 == 0) ? (size_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (size_t)blockIdx.x;
     const size_t stride = (size_t)gridDim.x * C::CPW;
     auto rec_issue = [&](size_t b) {
         // records lie in tiles of 8 cells, [tile][pair][cell % 8] (hho_pre.hpp): the pairs of one record are 128 bytes apart
