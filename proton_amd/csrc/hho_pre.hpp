@@ -15,6 +15,10 @@
 #pragma once
 #include "hho_device.hpp"
 
+// occupancy the pre-pass is compiled for (2nd __launch_bounds__ argument; 1 = whatever its registers allow)
+#ifndef PA_PRE_WAVES
+#define PA_PRE_WAVES 1
+#endif
 namespace pa {
 
 struct PreArgs {
@@ -26,7 +30,7 @@ struct PreArgs {
 };
 
 template <class C>
-__global__ __launch_bounds__(64) void hho_cell_pre_kernel(PreArgs a)
+__global__ __launch_bounds__(64, PA_PRE_WAVES) void hho_cell_pre_kernel(PreArgs a)
 {
     constexpr int RD = C::RD, RBS = C::RBS, NR = C::NR, NPW = C::NPW, NMOM = C::NMOM;
     typedef typename C::Pre PL;
