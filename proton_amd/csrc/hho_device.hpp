@@ -49,24 +49,32 @@
 #define PA_USE_PRE 1
 #endif
 
+// A/B switches of measured design choices; the defaults are what ships:
+// msize from which the lc-only kernel stores its accumulators straight to HBM instead of through an LDS image
 #ifndef PA_DIRECT_MIN
 #define PA_DIRECT_MIN 14
 #endif
+// 1: lc = Z^T Z with vector FMAs also when only lc is wanted (the matrix pipe is 15 ... 50 % faster)
 #ifndef PA_LC_VALU
 #define PA_LC_VALU 0
 #endif
+// bottom-right tile of Z^T Z (msize 17..24) on the vector pipe
 #ifndef PA_CORNER_VALU
 #define PA_CORNER_VALU 1
 #endif
+// cell part of U formed by (face, column) units instead of by the column owners
 #ifndef PA_UNIT_U
 #define PA_UNIT_U 1
 #endif
+// dense fancy instances (celdeg != recdeg) take mass rows + chol(M1) from the pre-pass record
 #ifndef PA_PRE_DENSE
 #define PA_PRE_DENSE 1
 #endif
+// k = 3 class: cell columns of gr_rhs on the matrix pipe
 #ifndef PA_GRC_MFMA
 #define PA_GRC_MFMA 1
 #endif
+// blocks of one XCD (blockIdx mod 8) take consecutive cells
 #ifndef PA_XCD_MAP
 #define PA_XCD_MAP 1
 #endif
