@@ -350,7 +350,7 @@ def main():
                        "note": w["note"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": li.kernel_name.decode() + (" + hho_cell_pre (its one-thread-per-cell pre-pass)" if w["stab"] != "fancy" or w["cd"] == w["fd"] + 1 else ""),
+                         "kernel": li.kernel_name.decode() + " + hho_cell_pre (its one-thread-per-cell pre-pass)",
                          "kernel_ms": kern_ms,
                          "kernel_ms_is": "HIP events around the local-operator launches of one step (pre-pass + cooperative kernel where the path is split: the sum of their rocprofv3 averages)",
                          "algorithmic_bytes_per_cell": bpc, "cells_per_launch": n_local,
