@@ -163,7 +163,8 @@ def test_batch_matches_oracle(asm, oracle, cd, fd, kind, stabname):
     assert nerr_cells(rhs2.cpu().numpy()[:, :, None], refr["rhs"][:, :, None]) < TOL
 
 
-@pytest.mark.parametrize("cd,fd,kind,stabname", [(3, 2, "tensor", "fancy"), (2, 1, "fan", "naive"), (4, 3, "tensor", "fancy")])
+@pytest.mark.parametrize("cd,fd,kind,stabname", [(3, 2, "tensor", "fancy"), (2, 1, "fan", "naive"), (4, 3, "tensor", "fancy"),
+                                                 (0, 1, "tensor", "fancy"), (2, 2, "tensor", "fancy")])      # the last two: dense fancy form
 def test_pre_pass_in_pieces(asm, oracle, cd, fd, kind, stabname, monkeypatch):
     """The split path (one-thread-per-cell pre-pass + cooperative kernel, hho_pre.hpp) runs in pieces when the record
     buffer is capped (PA_PRE_BYTES; 1 GiB by default, i.e. pieces from 1-2 M cells on): same results piece by piece,
