@@ -160,6 +160,80 @@ int pa_static_condensation_packed_batch(pa_context *ctx, pa_degree_info di, size
                                         const double *d_lc, const double *d_rhs,
                                         double *d_Sp, double *d_g, int32_t *d_info);
 
+/* ---- condensed mode: static condensation fused into the local-operator pass ---------------------
+ * The north star's hot path ends in the static condensation of the cell unknowns (SURVEY section 8 row
+ * A15; the reference has none: its assemblers keep cell AND face unknowns, hho.hpp:331).  In this mode
+ * lc = data + stab never reaches HBM: the kernel eliminates the cbs cell unknowns of every cell on chip
+ * and writes, per cell, one packed record of  nf (nf + 1) / 2 + nf  doubles (nf = 4 fbs):
+ *   the upper triangle of  S = A_FF - A_FT A_TT^-1 A_TF,  column-packed (S(i,j), i <= j, at j(j+1)/2 + i),
+ *   then  g = -A_FT A_TT^-1 f_T.
+ * d_rhs: f_T = make_rhs (utils.hpp:153-174), n x cbs, or NULL (= 0).  d_cond: n x (nf(nf+1)/2 + nf).
+ * d_info as pa_local_ops_batch; 200 + j flags pivot j of A_TT.  stab_kind must not be PA_STAB_NONE
+ * (A_TT = data_TT is singular on the constants, hho.hpp:93). */
+int pa_condensed_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind,
+                           size_t first, size_t n, const double *d_rhs, double *d_cond, int32_t *d_info);
+/* The same pass run for the recovery of the eliminated unknowns once the face unknowns are known:
+ *   u_T = A_TT^-1 (f_T - A_TF u_F)      d_uF: n x nf (pa_condensed_take_faces), d_uT: n x cbs. */
+int pa_condensed_recover_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind,
+                               size_t first, size_t n, const double *d_rhs, const double *d_uF,
+                               double *d_uT, int32_t *d_info);
+
+/* The face-only global system the condensed records assemble into: the reference's numbering
+ * (hho.hpp:305-331, 362-379) without its cbs * ncells block of cell unknowns -- unknown k of
+ * non-Dirichlet face F sits at compress_table[F] * fbs + k. */
+typedef struct {
+    uint64_t system_size;        /* fbs * num_other_faces                                            */
+    uint64_t num_other_faces;
+    int32_t nf, cond_doubles;    /* 4 fbs; nf (nf + 1) / 2 + nf                                     */
+    /* row partition: the context OWNS the rows of the faces of its cell rows' blocks (for every cell
+     * row its bottom and vertical faces; the horizontals closing the slab on top belong to the slab
+     * above): the contiguous row range [row_begin, row_end) of the global system */
+    uint64_t row_begin, row_end;
+    uint64_t nnz_owned;          /* stored entries of the owned rows                                 */
+    uint64_t halo_cells;         /* cells whose top face belongs to the slab above (Nx, or 0 for the
+                                    topmost slab): pa_condensed_halo_pack writes that many rows      */
+    int32_t halo_doubles;        /* doubles per halo row: fbs * (nf + 1)                             */
+    int32_t has_below;           /* != 0: the slab's bottom faces also receive the contribution of the
+                                    slab below: pa_condensed_csr_fill expects d_halo_below            */
+} pa_condensed_info;
+int pa_condensed_query(pa_context *ctx, pa_degree_info di, pa_condensed_info *out);
+
+/* assembler::assemble (hho.hpp:344-406) on the condensed blocks, cells [first, first+n): per cell nf^2
+ * triplet slots in the reference's push order restricted to the face unknowns (slot i*nf + j for face
+ * rows i, j of the local matrix), row = col = -1 where either face is Dirichlet; d_rhs_rows / d_rhs_vals
+ * n x nf: g_i minus the Dirichlet columns times the boundary data (hho.hpp:401).  d_g from
+ * pa_dirichlet_data_batch or NULL. */
+int pa_condensed_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n,
+                                const double *d_cond, const double *d_g,
+                                int32_t *d_rows, int32_t *d_cols, double *d_vals,
+                                int32_t *d_rhs_rows, double *d_rhs_vals);
+/* The same system built directly in CSR from the mesh's face adjacency -- no triplets, no sort.
+ * Symbolic phase, once per mesh and degree: d_rowptr (row_end - row_begin + 1 entries, int64, starting
+ * at 0) and d_colind (nnz_owned global column ids, ascending within a row). */
+int pa_condensed_csr_pattern(pa_context *ctx, pa_degree_info di, int64_t *d_rowptr, int32_t *d_colind);
+/* Numeric phase, once per assembly: d_values (nnz_owned) and d_rhs (row_end - row_begin) from the
+ * records of ALL the context's cells (d_cond: ncells x cond_doubles).  Contributions of the two cells of
+ * a face are added lower cell id first, the order setFromTriplets sums the triplets above in: values are
+ * bit-identical to pa_csr_from_triplets of pa_condensed_triplets_batch.  d_halo_below: the rows packed by
+ * the slab below (has_below), else NULL. */
+int pa_condensed_csr_fill(pa_context *ctx, pa_degree_info di, const double *d_cond, const double *d_g,
+                          const double *d_halo_below, double *d_values, double *d_rhs);
+/* What the slab above needs of this slab: for every cell of the top cell row the fbs rows of its top
+ * face -- fbs x nf values S(2 fbs + k, :) with Dirichlet columns already moved to the right-hand side,
+ * then the fbs right-hand-side contributions; halo_cells x halo_doubles doubles.  These rows are the
+ * whole multi-GPU exchange of an assembly step (pa_comm_* below). */
+int pa_condensed_halo_pack(pa_context *ctx, pa_degree_info di, const double *d_cond, const double *d_g, double *d_halo);
+/* take_local_data (hho.hpp:408-449) restricted to the faces: d_uF n x nf from the face-only solution
+ * (system_size values), Dirichlet faces from d_g. */
+int pa_condensed_take_faces(pa_context *ctx, pa_degree_info di, size_t first, size_t n,
+                            const double *d_solution, const double *d_g, double *d_uF);
+/* The reference's full solution vector (cells first, then compressed faces; hho.hpp:331) from the
+ * recovered cell unknowns (ncells x cbs, the context's cells) and the face-only solution: what
+ * assembler::take_local_data and the postprocessing expect.  d_full: cbs * ncells_global + system_size;
+ * a slab writes its own cells and (d_xF != NULL) the face part. */
+int pa_condensed_expand_solution(pa_context *ctx, pa_degree_info di, const double *d_uT, const double *d_xF,
+                                 double *d_full);
+
 /* ---- assembler<Mesh> (hho.hpp:252-463) ---------------------------------------------------
  * Face connectivity.  pa_mesh_generate builds it in closed form; for an uploaded mesh supply
  * msh.faces as the reference holds them (basic_mesh.hpp:114-137, sorted by (lo,hi) point ids):

@@ -1,7 +1,8 @@
 """Build libproton_amd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
 One translation unit per (cell degree, face degree, quadrature kind) listed in
-csrc/pa_configs.def, compiled in parallel, plus csrc/capi.hip, csrc/csr.hip and csrc/solver.hip; linked into
+csrc/pa_configs.def, compiled in parallel, plus csrc/capi.hip, csrc/csr.hip, csrc/solver.hip and
+csrc/condensed.hip; linked into
 proton_amd/lib/libproton_amd.so.  hipcc cross-compiles without a GPU.
 """
 import concurrent.futures
@@ -81,7 +82,7 @@ def build(force=False, verbose=False, jobs=None):
                          ["-DPA_CD=%d" % cd, "-DPA_FD=%d" % fd, "-DPA_QUAD=%d" % q, "-DPA_GMIN=%d" % gmin] +
                          ([] if os.environ.get("PA_WAVES_PER_EU") or os.environ.get("PA_EXTRA_FLAGS")
                           else PER_CONFIG_FLAGS.get((cd, fd, q), []))))
-    for unit in ("capi", "csr", "solver"):
+    for unit in ("capi", "csr", "solver", "condensed"):
         unit_obj = os.path.join(OBJ_DIR, unit + ".o")
         objs.append(unit_obj)
         if force or not os.path.exists(unit_obj) or os.path.getmtime(unit_obj) < newest:

@@ -92,6 +92,86 @@ class BatchAssembler:
                                      info.data_ptr())
         return S, g, rec, info
 
+    # ---- condensed mode (static condensation fused into the local-operator pass) ------
+    def condensed_ops(self, cd, fd, quad=capi.QUAD_TENSOR, stab=capi.STAB_FANCY, rhs=None, first=0, n=None, out=None, want_info=False):
+        """-> packed records [n, nf(nf+1)/2 + nf]: upper triangle of the Schur complement (column-packed), then g."""
+        di, _ = capi.degree_info(cd, fd)
+        n = self.ncells - first if n is None else n
+        nf = 4 * (di.face_deg + 1)
+        if out is None:
+            out = torch.empty((n, nf * (nf + 1) // 2 + nf), dtype=torch.float64, device=self.device)
+        info = torch.empty(n, dtype=torch.int32, device=self.device) if want_info else None
+        self.ctx.condensed_ops(di, quad, stab, first, n, _ptr(rhs), out.data_ptr(), _ptr(info))
+        return (out, info) if want_info else out
+
+    def condensed_recover(self, cd, fd, uF, quad=capi.QUAD_TENSOR, stab=capi.STAB_FANCY, rhs=None, first=0, n=None):
+        """u_T = A_TT^-1 (f_T - A_TF u_F) for cells [first, first+n) -> [n, cbs]."""
+        di, _ = capi.degree_info(cd, fd)
+        n = self.ncells - first if n is None else n
+        cbs = (di.cell_deg + 1) * (di.cell_deg + 2) // 2
+        uT = torch.empty((n, cbs), dtype=torch.float64, device=self.device)
+        self.ctx.condensed_recover(di, quad, stab, first, n, _ptr(rhs), uF.data_ptr(), uT.data_ptr(), None)
+        return uT
+
+    def condensed_info(self, cd, fd):
+        di, _ = capi.degree_info(cd, fd)
+        return self.ctx.condensed_query(di)
+
+    def condensed_triplets(self, cd, fd, cond, g=None, first=0):
+        di, _ = capi.degree_info(cd, fd)
+        n, nf = cond.shape[0], 4 * (di.face_deg + 1)
+        rows = torch.empty((n, nf * nf), dtype=torch.int32, device=self.device)
+        cols = torch.empty((n, nf * nf), dtype=torch.int32, device=self.device)
+        vals = torch.empty((n, nf * nf), dtype=torch.float64, device=self.device)
+        rhs_rows = torch.empty((n, nf), dtype=torch.int32, device=self.device)
+        rhs_vals = torch.empty((n, nf), dtype=torch.float64, device=self.device)
+        self.ctx.condensed_triplets(di, first, n, cond.data_ptr(), _ptr(g), rows.data_ptr(), cols.data_ptr(), vals.data_ptr(),
+                                    rhs_rows.data_ptr(), rhs_vals.data_ptr())
+        return rows, cols, vals, rhs_rows, rhs_vals
+
+    def condensed_csr_pattern(self, cd, fd):
+        """symbolic phase -> (rowptr int64 [rows+1], colind int32 [nnz]) of the rows this context owns"""
+        di, _ = capi.degree_info(cd, fd)
+        ci = self.ctx.condensed_query(di)
+        rowptr = torch.empty(ci.row_end - ci.row_begin + 1, dtype=torch.int64, device=self.device)
+        colind = torch.empty(max(ci.nnz_owned, 1), dtype=torch.int32, device=self.device)
+        self.ctx.condensed_csr_pattern(di, rowptr.data_ptr(), colind.data_ptr())
+        return rowptr, colind[:ci.nnz_owned]
+
+    def condensed_csr_fill(self, cd, fd, cond, g=None, halo_below=None, values=None, rhs=None):
+        """numeric phase -> (values [nnz], rhs [rows])"""
+        di, _ = capi.degree_info(cd, fd)
+        ci = self.ctx.condensed_query(di)
+        if values is None:
+            values = torch.empty(max(ci.nnz_owned, 1), dtype=torch.float64, device=self.device)
+        if rhs is None:
+            rhs = torch.empty(max(ci.row_end - ci.row_begin, 1), dtype=torch.float64, device=self.device)
+        self.ctx.condensed_csr_fill(di, cond.data_ptr(), _ptr(g), _ptr(halo_below), values.data_ptr(), rhs.data_ptr())
+        return values[:ci.nnz_owned], rhs[:ci.row_end - ci.row_begin]
+
+    def condensed_halo_pack(self, cd, fd, cond, g=None, out=None):
+        di, _ = capi.degree_info(cd, fd)
+        ci = self.ctx.condensed_query(di)
+        if out is None:
+            out = torch.empty((max(ci.halo_cells, 1), ci.halo_doubles), dtype=torch.float64, device=self.device)
+        self.ctx.condensed_halo_pack(di, cond.data_ptr(), _ptr(g), out.data_ptr())
+        return out[:ci.halo_cells]
+
+    def condensed_take_faces(self, cd, fd, solution, g=None, first=0, n=None):
+        di, _ = capi.degree_info(cd, fd)
+        n = self.ncells - first if n is None else n
+        uF = torch.empty((n, 4 * (di.face_deg + 1)), dtype=torch.float64, device=self.device)
+        self.ctx.condensed_take_faces(di, first, n, solution.data_ptr(), _ptr(g), uF.data_ptr())
+        return uF
+
+    def condensed_expand_solution(self, cd, fd, uT, xF, full=None):
+        di, _ = capi.degree_info(cd, fd)
+        info = self.ctx.assembler_query(di)
+        if full is None:
+            full = torch.zeros(info.system_size, dtype=torch.float64, device=self.device)
+        self.ctx.condensed_expand_solution(di, uT.data_ptr(), _ptr(xF), full.data_ptr())
+        return full
+
     # ---- assembler (hho.hpp:252-463) -------------------------------------------------
     def set_faces(self, cell_faces, face_pts, face_is_dirichlet):
         self.ctx.mesh_set_faces(cell_faces, face_pts, face_is_dirichlet)

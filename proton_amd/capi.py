@@ -32,6 +32,9 @@ EXPORTS = [
     "pa_cut_preprocess_agglomeration", "pa_cut_agglo_query", "pa_cut_query_tags", "pa_cut_quadrature_points", "pa_cut_rhs_sampled_batch",
     "pa_cut_interface_ops_batch", "pa_cut_interface_uncut_batch", "pa_interface_assembler_query",
     "pa_interface_triplets_batch", "pa_interface_cell_offsets",
+    "pa_condensed_ops_batch", "pa_condensed_recover_batch", "pa_condensed_query", "pa_condensed_triplets_batch",
+    "pa_condensed_csr_pattern", "pa_condensed_csr_fill", "pa_condensed_halo_pack", "pa_condensed_take_faces",
+    "pa_condensed_expand_solution",
 ]
 
 
@@ -60,6 +63,12 @@ class LaunchInfo(C.Structure):
 class AssemblerInfo(C.Structure):
     _fields_ = [("system_size", C.c_uint64), ("ncells_global", C.c_uint64), ("cell_base", C.c_uint64),
                 ("nfaces_local", C.c_uint64), ("face_base", C.c_uint64), ("num_other_faces", C.c_uint64)]
+
+
+class CondensedInfo(C.Structure):
+    _fields_ = [("system_size", C.c_uint64), ("num_other_faces", C.c_uint64), ("nf", C.c_int32), ("cond_doubles", C.c_int32),
+                ("row_begin", C.c_uint64), ("row_end", C.c_uint64), ("nnz_owned", C.c_uint64), ("halo_cells", C.c_uint64),
+                ("halo_doubles", C.c_int32), ("has_below", C.c_int32)]
 
 
 class LevelSet(C.Structure):
@@ -152,6 +161,15 @@ def lib():
     L.pa_interface_assembler_query.argtypes = [vp, C.c_int, C.POINTER(InterfaceInfo)]
     L.pa_interface_triplets_batch.argtypes = [vp, C.c_int] + [dp] * 15
     L.pa_interface_cell_offsets.argtypes = [vp, C.c_int, dp]
+    L.pa_condensed_ops_batch.argtypes = [vp, DegreeInfo, C.c_int, C.c_int, sz, sz, dp, dp, dp]
+    L.pa_condensed_recover_batch.argtypes = [vp, DegreeInfo, C.c_int, C.c_int, sz, sz, dp, dp, dp, dp]
+    L.pa_condensed_query.argtypes = [vp, DegreeInfo, C.POINTER(CondensedInfo)]
+    L.pa_condensed_triplets_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp, dp, dp, dp, dp]
+    L.pa_condensed_csr_pattern.argtypes = [vp, DegreeInfo, dp, dp]
+    L.pa_condensed_csr_fill.argtypes = [vp, DegreeInfo, dp, dp, dp, dp, dp]
+    L.pa_condensed_halo_pack.argtypes = [vp, DegreeInfo, dp, dp, dp]
+    L.pa_condensed_take_faces.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp]
+    L.pa_condensed_expand_solution.argtypes = [vp, DegreeInfo, dp, dp, dp]
     _lib = L
     return L
 
@@ -371,6 +389,37 @@ class Context:
 
     def cut_merge(self, face_deg, where, cut_lc, cut_rhs, lc, rhs):
         self._ck(self._L.pa_cut_merge(self.h, face_deg, where, cut_lc, cut_rhs, lc, rhs), "pa_cut_merge")
+
+    # ---- condensed mode --------------------------------------------------------------
+    def condensed_ops(self, di, quad, stab, first, n, rhs, cond, info=None):
+        self._ck(self._L.pa_condensed_ops_batch(self.h, di, quad, stab, first, n, rhs, cond, info), "pa_condensed_ops_batch")
+
+    def condensed_recover(self, di, quad, stab, first, n, rhs, uF, uT, info=None):
+        self._ck(self._L.pa_condensed_recover_batch(self.h, di, quad, stab, first, n, rhs, uF, uT, info), "pa_condensed_recover_batch")
+
+    def condensed_query(self, di):
+        out = CondensedInfo()
+        self._ck(self._L.pa_condensed_query(self.h, di, C.byref(out)), "pa_condensed_query")
+        return out
+
+    def condensed_triplets(self, di, first, n, cond, g, rows, cols, vals, rhs_rows, rhs_vals):
+        self._ck(self._L.pa_condensed_triplets_batch(self.h, di, first, n, cond, g, rows, cols, vals, rhs_rows, rhs_vals),
+                 "pa_condensed_triplets_batch")
+
+    def condensed_csr_pattern(self, di, rowptr, colind):
+        self._ck(self._L.pa_condensed_csr_pattern(self.h, di, rowptr, colind), "pa_condensed_csr_pattern")
+
+    def condensed_csr_fill(self, di, cond, g, halo_below, values, rhs):
+        self._ck(self._L.pa_condensed_csr_fill(self.h, di, cond, g, halo_below, values, rhs), "pa_condensed_csr_fill")
+
+    def condensed_halo_pack(self, di, cond, g, halo):
+        self._ck(self._L.pa_condensed_halo_pack(self.h, di, cond, g, halo), "pa_condensed_halo_pack")
+
+    def condensed_take_faces(self, di, first, n, solution, g, uF):
+        self._ck(self._L.pa_condensed_take_faces(self.h, di, first, n, solution, g, uF), "pa_condensed_take_faces")
+
+    def condensed_expand_solution(self, di, uT, xF, full):
+        self._ck(self._L.pa_condensed_expand_solution(self.h, di, uT, xF, full), "pa_condensed_expand_solution")
 
     def launch_info(self, di, quad, stab, n):
         li = LaunchInfo()

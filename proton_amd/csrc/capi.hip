@@ -13,6 +13,7 @@
 #include "../../include/proton_amd.h"
 #include "cut_device.hpp"
 #include "cut_interface_device.hpp"
+#include "condensed.hpp"
 #include "cut_host.hpp"
 #include "hho_assembly.hpp"
 #include "hho_aux.hpp"
@@ -84,6 +85,17 @@ struct pa_context {
     uint8_t *d_face_dir = nullptr;
     int32_t *d_face_compress = nullptr;
     size_t nfaces_local = 0, face_base = 0, num_other_faces = 0, ncells_global = 0, cell_base = 0;
+    // generator mesh (pa_mesh_generate / pa_cut_preprocess): the slab in closed form
+    pa::StructuredMesh sm = {0, 0, 0, 0};
+    bool structured = false;
+    // condensed (face-only) assembly: face adjacency and the symbolic records of the owned faces, built on first use
+    int32_t *d_adj = nullptr;
+    pa::CondFace *d_cfaces = nullptr;
+    uint32_t *d_ncols = nullptr, *d_prefix = nullptr;
+    bool cond_ready = false;
+    uint32_t cond_nown = 0, cond_owned_range = 0;
+    int32_t cond_p0 = 0;
+    uint64_t cond_total_cols = 0;             // sum of the column-face counts of the owned faces
     // cutHHO state (host tags + device copies)
     pa::CutMeshHost *cut = nullptr;
     // device copies of the cut quadrature lists, built once per (face degree, side)
@@ -126,6 +138,13 @@ static void release_faces(pa_context *ctx)
     if (ctx->d_face_compress) (void)hipFree(ctx->d_face_compress);
     ctx->d_cell_faces = ctx->d_face_pts = nullptr; ctx->d_face_dir = nullptr; ctx->d_face_compress = nullptr;
     ctx->nfaces_local = ctx->face_base = ctx->num_other_faces = 0;
+    if (ctx->d_adj) (void)hipFree(ctx->d_adj);
+    if (ctx->d_cfaces) (void)hipFree(ctx->d_cfaces);
+    if (ctx->d_ncols) (void)hipFree(ctx->d_ncols);
+    if (ctx->d_prefix) (void)hipFree(ctx->d_prefix);
+    ctx->d_adj = nullptr; ctx->d_cfaces = nullptr; ctx->d_ncols = ctx->d_prefix = nullptr;
+    ctx->cond_ready = false; ctx->cond_nown = ctx->cond_owned_range = 0; ctx->cond_p0 = 0; ctx->cond_total_cols = 0;
+    ctx->structured = false;
 }
 
 static void release_cut_lists(pa_context *ctx, int slot)
@@ -393,6 +412,7 @@ int pa_mesh_generate(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double
                        ctx->d_face_pts, ctx->d_face_dir, ctx->d_face_compress, (uint32_t)nc, ctx->d_cell_faces);
     PA_HIP(ctx, hipGetLastError());
     ctx->nfaces_local = nfl; ctx->face_base = pa::sm_face_base(sm); ctx->num_other_faces = pa::sm_num_other_faces(sm);
+    ctx->sm = sm; ctx->structured = true;
     return PA_OK;
 }
 
@@ -648,7 +668,7 @@ static int pick_lanes(int cd, int fd, int quad)
 }
 
 static int select_kernel(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t n,
-                         const pa::KernelEntry **entry, int *grid)
+                         const pa::KernelEntry **entry, int *grid, bool cond = false)
 {
     pa_sizes sz;
     const int st = pa_sizes_for(di, quad_kind, &sz);
@@ -656,9 +676,10 @@ static int select_kernel(pa_context *ctx, pa_degree_info di, int quad_kind, int 
     if (stab_kind < PA_STAB_NONE || stab_kind > PA_STAB_FANCY) return PA_ERR_INVALID_ARG;
     const int lanes = pick_lanes(di.cell_deg, di.face_deg, quad_kind);
     const pa::KernelEntry *e = lanes ? find_kernel(di.cell_deg, di.face_deg, quad_kind, stab_kind, lanes) : nullptr;
-    if (!e) return PA_ERR_INVALID_DEGREE;
+    if (!e || (cond && !e->launch_cond)) return PA_ERR_INVALID_DEGREE;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, e->func, 64, e->lds_bytes) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cond ? e->func_cond : e->func, 64,
+                                                     cond ? e->lds_bytes_cond : e->lds_bytes) != hipSuccess || per_cu < 1)
         per_cu = 1;
     // A persistent grid of exactly waves_per_simd x 4 blocks per CU: when the compiler needs fewer registers than
     // the launch bound allows the hardware could hold more, and more was measured to be slower (msize 9: +24 %)
@@ -677,20 +698,33 @@ static int select_kernel(pa_context *ctx, pa_degree_info di, int quad_kind, int 
     return PA_OK;
 }
 
-int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t first, size_t n,
-                       double *d_oper, double *d_data, double *d_stab, double *d_lc, int32_t *d_info)
+// outputs of one pass over cells [first, first + n): the local-operator modes write oper / data / stab / lc, the
+// condensed mode (cond) reads rhs (and uF) and writes the packed condensed records (or uT)
+struct LocalOpsOut {
+    double *oper = nullptr, *data = nullptr, *stab = nullptr, *lc = nullptr;
+    int32_t *info = nullptr;
+    bool cond = false;
+    const double *rhs = nullptr, *uF = nullptr;
+    double *cond_out = nullptr, *uT = nullptr;
+};
+
+static int run_local_ops(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t first, size_t n,
+                         const LocalOpsOut &o)
 {
+    double *d_oper = o.oper, *d_data = o.data, *d_stab = o.stab, *d_lc = o.lc;
+    int32_t *d_info = o.info;
     if (!ctx) return PA_ERR_INVALID_ARG;
     if (!ctx->d_points) return PA_ERR_NO_MESH;
     if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
+    PA_HIP(ctx, hipSetDevice(ctx->device));
     const pa::KernelEntry *e = nullptr;
     int grid = 0;
-    const int st = select_kernel(ctx, di, quad_kind, stab_kind, n, &e, &grid);
+    const int st = select_kernel(ctx, di, quad_kind, stab_kind, n, &e, &grid, o.cond);
     if (st != PA_OK) return st;
     if (n == 0) return PA_OK;
     uint32_t ablate = 0;
     if (const char *env = std::getenv("PA_ABLATE")) ablate = (uint32_t)std::strtoul(env, nullptr, 0);   // profiling only
-    const bool split = d_data != nullptr || d_stab != nullptr;
+    const bool split = !o.cond && (d_data != nullptr || d_stab != nullptr);
     // Kernels that take the per-cell head from the pre-pass run in pieces of at most `piece` cells: pre-pass of a
     // piece into the context's record buffer, then the cooperative kernel over the same cells (same stream).
     size_t piece = n;
@@ -719,7 +753,7 @@ int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int st
         int g = grid;
         if (m != n) {
             const pa::KernelEntry *e2 = nullptr;
-            const int st2 = select_kernel(ctx, di, quad_kind, stab_kind, m, &e2, &g);
+            const int st2 = select_kernel(ctx, di, quad_kind, stab_kind, m, &e2, &g, o.cond);
             if (st2 != PA_OK) return st2;
         }
         pa::LocalOpsArgs a;
@@ -738,6 +772,11 @@ int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int st
         a.stab = d_stab ? d_stab + off * mm : nullptr;
         a.lc = d_lc ? d_lc + off * mm : nullptr;
         a.info = d_info ? d_info + off : nullptr;
+        const size_t ncond = (size_t)(4 * sz.fbs) * (size_t)(4 * sz.fbs + 1) / 2 + (size_t)(4 * sz.fbs);
+        a.rhs = o.rhs ? o.rhs + off * (size_t)sz.cbs : nullptr;
+        a.cond = o.cond_out ? o.cond_out + off * ncond : nullptr;
+        a.uF = o.uF ? o.uF + off * (size_t)(4 * sz.fbs) : nullptr;
+        a.uT = o.uT ? o.uT + off * (size_t)sz.cbs : nullptr;
         a.ablate = ablate;
         a.dbg = nullptr;
 #ifdef PA_STAGE_CLOCK
@@ -748,7 +787,7 @@ int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int st
         (void)hipMemsetAsync(d_dbg, 0, ndbg * sizeof(long long), ctx->stream);
         a.dbg = d_dbg;
 #endif
-        PA_HIP(ctx, (split ? e->launch_split : e->launch)(a, g, ctx->stream));
+        PA_HIP(ctx, (o.cond ? e->launch_cond : split ? e->launch_split : e->launch)(a, g, ctx->stream));
 #ifdef PA_STAGE_CLOCK
         {
             std::vector<long long> h(ndbg);
@@ -764,6 +803,34 @@ int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int st
 #endif
     }
     return PA_OK;
+}
+
+int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t first, size_t n,
+                       double *d_oper, double *d_data, double *d_stab, double *d_lc, int32_t *d_info)
+{
+    LocalOpsOut o;
+    o.oper = d_oper; o.data = d_data; o.stab = d_stab; o.lc = d_lc; o.info = d_info;
+    return run_local_ops(ctx, di, quad_kind, stab_kind, first, n, o);
+}
+
+int pa_condensed_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t first, size_t n,
+                           const double *d_rhs, double *d_cond, int32_t *d_info)
+{
+    if (!d_cond) return PA_ERR_INVALID_ARG;
+    if (stab_kind == PA_STAB_NONE) return PA_ERR_INVALID_ARG;      // A_TT = data_TT is singular (constants)
+    LocalOpsOut o;
+    o.cond = true; o.rhs = d_rhs; o.cond_out = d_cond; o.info = d_info;
+    return run_local_ops(ctx, di, quad_kind, stab_kind, first, n, o);
+}
+
+int pa_condensed_recover_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t first, size_t n,
+                               const double *d_rhs, const double *d_uF, double *d_uT, int32_t *d_info)
+{
+    if (!d_uF || !d_uT) return PA_ERR_INVALID_ARG;
+    if (stab_kind == PA_STAB_NONE) return PA_ERR_INVALID_ARG;
+    LocalOpsOut o;
+    o.cond = true; o.rhs = d_rhs; o.uF = d_uF; o.uT = d_uT; o.info = d_info;
+    return run_local_ops(ctx, di, quad_kind, stab_kind, first, n, o);
 }
 
 int pa_local_ops_launch_info(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t n, pa_launch_info *out)
@@ -964,6 +1031,151 @@ static int condense(pa_context *ctx, pa_degree_info di, size_t n, const double *
     PA_SC_CASE(2, 2) PA_SC_CASE(1, 2) PA_SC_CASE(4, 3) PA_SC_CASE(3, 3) PA_SC_CASE(2, 3)
 #undef PA_SC_CASE
     return PA_ERR_INVALID_DEGREE;
+}
+
+// ---- condensed (face-only) system -----------------------------------------------------------------
+static bool cond_degree_ok(pa_degree_info di) { return di.cell_deg >= 0 && di.cell_deg <= 4 && di.face_deg >= 0 && di.face_deg <= 3; }
+
+static pa::CondMesh cond_mesh(const pa_context *ctx)
+{
+    pa::CondMesh m;
+    m.cell_faces = ctx->d_cell_faces; m.face_compress = ctx->d_face_compress; m.adj = ctx->d_adj;
+    m.sm = ctx->sm; m.structured = ctx->structured;
+    return m;
+}
+
+// first compressed id at or after global face `gid` of the generator mesh (the compress table is monotone)
+static int32_t sm_first_compress_from(const pa::StructuredMesh &sm, uint32_t gid)
+{
+    const uint32_t nfaces = sm.Ny * pa::sm_face_row(sm) + sm.Nx;
+    for (uint32_t f = gid; f < nfaces; ++f) {
+        uint32_t lo, hi; bool d; int32_t comp;
+        pa::sm_face_decode(sm, f, lo, hi, d, comp);
+        if (!d) return comp;
+    }
+    return (int32_t)pa::sm_num_other_faces(sm);
+}
+
+// symbolic phase, cached per mesh: adjacency, owned faces, their column faces
+static int cond_prepare(pa_context *ctx)
+{
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    if (ctx->cond_ready) return PA_OK;
+    PA_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t owned_range, nown; int32_t p0;
+    if (ctx->structured) {
+        const pa::StructuredMesh &sm = ctx->sm;
+        owned_range = (sm.row1 - sm.row0) * pa::sm_face_row(sm);
+        p0 = sm_first_compress_from(sm, sm.row0 * pa::sm_face_row(sm));
+        const int32_t p1 = sm_first_compress_from(sm, sm.row1 * pa::sm_face_row(sm));
+        nown = (uint32_t)(p1 - p0);
+    } else {
+        owned_range = (uint32_t)ctx->nfaces_local; p0 = 0; nown = (uint32_t)ctx->num_other_faces;
+    }
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_adj, (ctx->nfaces_local ? ctx->nfaces_local : 1) * 2 * sizeof(int32_t)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_cfaces, ((size_t)nown + 1) * sizeof(pa::CondFace)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_ncols, ((size_t)nown + 1) * sizeof(uint32_t)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_prefix, ((size_t)nown + 1) * sizeof(uint32_t)));
+    PA_HIP(ctx, pa::cond_build_tables(ctx->stream, cond_mesh(ctx), (uint32_t)ctx->nfaces_local, (uint32_t)ctx->ncells, owned_range, p0,
+                                      nown, ctx->d_adj, ctx->d_cfaces, ctx->d_ncols, ctx->d_prefix));
+    uint32_t total = 0;
+    PA_HIP(ctx, hipMemcpy(&total, ctx->d_prefix + nown, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    ctx->cond_nown = nown; ctx->cond_owned_range = owned_range; ctx->cond_p0 = p0; ctx->cond_total_cols = total;
+    ctx->cond_ready = true;
+    return PA_OK;
+}
+
+int pa_condensed_query(pa_context *ctx, pa_degree_info di, pa_condensed_info *out)
+{
+    if (!ctx || !out || !cond_degree_ok(di)) return PA_ERR_INVALID_ARG;
+    const int st = cond_prepare(ctx);
+    if (st != PA_OK) return st;
+    const uint64_t fbs = (uint64_t)di.face_deg + 1;
+    out->num_other_faces = ctx->num_other_faces;
+    out->system_size = fbs * ctx->num_other_faces;
+    out->nf = (int32_t)(4 * fbs);
+    out->cond_doubles = (int32_t)(4 * fbs * (4 * fbs + 1) / 2 + 4 * fbs);
+    out->row_begin = (uint64_t)ctx->cond_p0 * fbs;
+    out->row_end = ((uint64_t)ctx->cond_p0 + ctx->cond_nown) * fbs;
+    out->nnz_owned = ctx->cond_total_cols * fbs * fbs;
+    out->halo_cells = (ctx->structured && ctx->sm.row1 < ctx->sm.Ny) ? ctx->sm.Nx : 0;
+    out->halo_doubles = (int32_t)(fbs * (4 * fbs + 1));
+    out->has_below = (ctx->structured && ctx->sm.row0 > 0) ? 1 : 0;
+    return PA_OK;
+}
+
+int pa_condensed_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n, const double *d_cond, const double *d_g,
+                                int32_t *d_rows, int32_t *d_cols, double *d_vals, int32_t *d_rhs_rows, double *d_rhs_vals)
+{
+    if (!ctx || !d_cond || !d_rows || !d_cols || !d_vals || !d_rhs_rows || !d_rhs_vals) return PA_ERR_INVALID_ARG;
+    if (!cond_degree_ok(di)) return PA_ERR_INVALID_DEGREE;
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
+    if ((uint64_t)(di.face_deg + 1) * ctx->num_other_faces >= ((uint64_t)1 << 31)) return PA_ERR_INVALID_ARG;      // int triplet indices
+    PA_HIP(ctx, hipSetDevice(ctx->device));
+    PA_HIP(ctx, pa::cond_triplets(ctx->stream, cond_mesh(ctx), ctx->num_cus, first, n, di.face_deg + 1, d_cond, d_g, d_rows, d_cols,
+                                  d_vals, d_rhs_rows, d_rhs_vals));
+    return PA_OK;
+}
+
+int pa_condensed_csr_pattern(pa_context *ctx, pa_degree_info di, int64_t *d_rowptr, int32_t *d_colind)
+{
+    if (!ctx || !d_rowptr || !cond_degree_ok(di)) return PA_ERR_INVALID_ARG;
+    const int st = cond_prepare(ctx);
+    if (st != PA_OK) return st;
+    if ((uint64_t)(di.face_deg + 1) * ctx->num_other_faces >= ((uint64_t)1 << 31)) return PA_ERR_INVALID_ARG;      // int32 column ids
+    PA_HIP(ctx, pa::cond_pattern(ctx->stream, ctx->cond_nown, di.face_deg + 1, ctx->d_cfaces, ctx->d_prefix, d_rowptr, d_colind));
+    return PA_OK;
+}
+
+int pa_condensed_csr_fill(pa_context *ctx, pa_degree_info di, const double *d_cond, const double *d_g, const double *d_halo_below,
+                          double *d_values, double *d_rhs)
+{
+    if (!ctx || !d_cond || !d_values || !cond_degree_ok(di)) return PA_ERR_INVALID_ARG;
+    const int st = cond_prepare(ctx);
+    if (st != PA_OK) return st;
+    if (ctx->structured && ctx->sm.row0 > 0 && !d_halo_below) {
+        ctx->last_error = "pa_condensed_csr_fill: this slab has a slab below: d_halo_below (pa_condensed_halo_pack of that slab) is required";
+        return PA_ERR_INVALID_ARG;
+    }
+    PA_HIP(ctx, hipSetDevice(ctx->device));
+    PA_HIP(ctx, pa::cond_fill(ctx->stream, cond_mesh(ctx), ctx->cond_nown, di.face_deg + 1, ctx->d_cfaces, ctx->d_prefix, d_cond, d_g,
+                              d_halo_below, d_values, d_rhs));
+    return PA_OK;
+}
+
+int pa_condensed_halo_pack(pa_context *ctx, pa_degree_info di, const double *d_cond, const double *d_g, double *d_halo)
+{
+    if (!ctx || !d_cond || !d_halo || !cond_degree_ok(di)) return PA_ERR_INVALID_ARG;
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    if (!ctx->structured || ctx->sm.row1 >= ctx->sm.Ny) return PA_OK;          // nothing above this slab
+    PA_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t Nx = ctx->sm.Nx;
+    PA_HIP(ctx, pa::cond_halo_pack(ctx->stream, cond_mesh(ctx), (uint32_t)ctx->ncells - Nx, Nx, di.face_deg + 1, d_cond, d_g, d_halo));
+    return PA_OK;
+}
+
+int pa_condensed_take_faces(pa_context *ctx, pa_degree_info di, size_t first, size_t n, const double *d_solution, const double *d_g,
+                            double *d_uF)
+{
+    if (!ctx || !d_solution || !d_uF) return PA_ERR_INVALID_ARG;
+    if (!cond_degree_ok(di)) return PA_ERR_INVALID_DEGREE;
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
+    PA_HIP(ctx, hipSetDevice(ctx->device));
+    PA_HIP(ctx, pa::cond_take_faces(ctx->stream, cond_mesh(ctx), first, n, di.face_deg + 1, d_solution, d_g, d_uF));
+    return PA_OK;
+}
+
+int pa_condensed_expand_solution(pa_context *ctx, pa_degree_info di, const double *d_uT, const double *d_xF, double *d_full)
+{
+    if (!ctx || !d_uT || !d_full) return PA_ERR_INVALID_ARG;
+    if (!cond_degree_ok(di)) return PA_ERR_INVALID_DEGREE;
+    if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    PA_HIP(ctx, hipSetDevice(ctx->device));
+    PA_HIP(ctx, pa::cond_expand(ctx->stream, ctx->ncells, ctx->cell_base, ctx->ncells_global, pa::P2(di.cell_deg),
+                                (size_t)(di.face_deg + 1) * ctx->num_other_faces, d_uT, d_xF, d_full));
+    return PA_OK;
 }
 
 // ---- cutHHO -----------------------------------------------------------------------------------

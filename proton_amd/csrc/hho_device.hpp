@@ -127,9 +127,12 @@ __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ constexpr int imin(int a, int b) { return a < b ? a : b; }
 __host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 
-template <int CD_, int FD_, int QUAD_, int STAB_, int G_>
+// COND_ = 1: the instance of the condensed mode (static condensation fused behind the product, no lc in HBM): its
+// region Q also holds the (MS + 1)-row image of [lc f_T; f_T^T 0] the partial factorization works on.
+template <int CD_, int FD_, int QUAD_, int STAB_, int G_, int COND_ = 0>
 struct Cfg {
     static constexpr int CD = CD_, FD = FD_, RD = FD_ + 1, QUAD = QUAD_, STAB = STAB_, G = G_;
+    static constexpr bool COND = COND_ != 0;
     static constexpr int RBS = P2(RD), CBS = P2(CD), FBS = FD + 1;
     static constexpr int NF = 4 * FBS, MS = CBS + NF, NR = RBS - 1;
     static constexpr int QDEG = 2 * RD;                       // hho.hpp:55,174
@@ -209,7 +212,14 @@ struct Cfg {
     static_assert(USE_PRE || SPC <= 1 || CBS * NRP <= 2 * NQ * NPW, "GRC must fit the dead quadrature tables");
     static constexpr int oZ = 0;                              // ZS x MS    (written from S5 on)
     static constexpr int oOUT = 0;                            // MS x MS    (written in S8, after the last read of Z)
-    static constexpr int sizeQ = imax(imax(endQ, ZS * MS), MS * MS);
+    // condensed mode: image of the symmetric matrix [lc f_T; f_T^T 0], row-major == column-major, even stride LDI;
+    // the packed result (upper triangle of S, then g) is staged on the rows of the cell block once they are dead, or
+    // behind the image where that block is too small (cbs <= 3)
+    static constexpr int LDI = (CBS + 4 * FBS + 2) & ~1;
+    static constexpr int NSP = NF * (NF + 1) / 2, NCOND = NSP + NF;
+    static constexpr int oSTG = CBS * LDI >= NCOND ? 0 : (MS + 1) * LDI;
+    static constexpr int condQ = (MS + 1) * LDI + (CBS * LDI >= NCOND ? 0 : NCOND);
+    static constexpr int sizeQ = imax(imax(endQ, ZS * MS), COND ? condQ : MS * MS);
     // region P: lives until the forward substitutions are done.  Stiffness, stride LD; its [1:,1:]
     // block becomes chol(gr_lhs) row by row: oST is odd so that the block (and every row of it)
     // starts on a 16-byte boundary
@@ -245,6 +255,14 @@ struct LocalOpsArgs {
     const double *pre;         // records of Cfg::Pre::NPRE doubles (hho_pre.hpp) in tiles of 8 cells; Cfg::USE_PRE only
     double *oper, *data, *stab, *lc;
     int32_t *info;
+    // condensed mode (MODE_COND): f_T per cell (n x cbs, may be null = 0) in; per cell the packed upper triangle of the
+    // Schur complement S = A_FF - A_FT A_TT^-1 A_TF (column-packed: S(i,j), i <= j, at j(j+1)/2 + i) followed by
+    // g = -A_FT A_TT^-1 f_T, NCOND = nf(nf+1)/2 + nf doubles, out.  With uF (n x nf) the same pass recovers the cell
+    // unknowns instead: uT = A_TT^-1 (f_T - A_TF uF) (n x cbs).
+    const double *rhs;
+    double *cond;
+    const double *uF;
+    double *uT;
     // Stage mask, 0 in production.  Profiling (PA_ABLATE): bit i skips stage i and the results are garbage.
     // It is ALSO load-bearing: the stages sit in branches on this runtime value, which the compiler cannot
     // prove taken, so it does not hoist their per-lane, cell-invariant subexpressions out of the cell loop.
@@ -574,12 +592,19 @@ __device__ __forceinline__ uint32_t sel4u(uint32_t v0, uint32_t v1, uint32_t v2,
 // -------------------------------------------------------------------------------------
 // The kernel.  One wavefront per block; G lanes per cell; persistent over cells.
 // -------------------------------------------------------------------------------------
-// SPLIT = false: only lc = data + stab is produced (one accumulator per entry);
-// SPLIT = true:  data and stab are kept apart so that any of lc / data / stab can be written.
-// (the SPLIT variant keeps two accumulator sets and the columns of Y and U in registers: at most 3 waves/SIMD)
-template <class C, bool SPLIT>
-__global__ __launch_bounds__(64, (SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hho_local_ops_kernel(LocalOpsArgs a)
+// MODE_LC:    only lc = data + stab is produced (one accumulator per entry);
+// MODE_SPLIT: data and stab are kept apart so that any of lc / data / stab can be written
+//             (two accumulator sets and the columns of Y and U in registers: at most 3 waves/SIMD);
+// MODE_COND:  lc never leaves the chip: the product lands in an LDS image and the cell unknowns are eliminated there
+//             (partial Cholesky of [lc f_T; f_T^T 0] over the cbs cell pivots); the packed Schur complement and the
+//             condensed right-hand side are the only output -- or, given the face unknowns, the recovered cell unknowns.
+enum { MODE_LC = 0, MODE_SPLIT = 1, MODE_COND = 2 };
+template <class C, int MODE>
+__global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hho_local_ops_kernel(LocalOpsArgs a)
 {
+    constexpr bool SPLIT = MODE == MODE_SPLIT, COND = MODE == MODE_COND;
+    static_assert(COND == C::COND, "the condensed mode runs on the Cfg instance that reserves its LDS image");
+    static_assert(!COND || (C::CBS + C::NF + 1 <= C::G && C::HAS_STAB), "condensed mode: one lane per row of [lc f_T; f_T^T 0]");
     constexpr int G = C::G, RBS = C::RBS, CBS = C::CBS, FBS = C::FBS, MS = C::MS, NR = C::NR, NF = C::NF;
     constexpr int NQ = C::NQ, NFQ = C::NFQ, NFP = C::NFP, NP = C::NP, RD = C::RD, NPW = C::NPW;
     constexpr int ZS = C::ZS, ND = C::ND, NRP = C::NRP, LD = C::LD;
@@ -745,6 +770,13 @@ __global__ __launch_bounds__(64, (SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hh
         asm volatile("" : "+v"(l));
         const bool valid = base + g < a.n;
         const size_t cell = a.first + (valid ? base + g : a.n - 1);
+        // condensed mode: the cell's right-hand side (lanes < CBS) and, for the recovery, its face unknowns (lanes < NF),
+        // one value per lane, in flight until the image phase
+        double fT_l = 0.0, uF_l = 0.0;
+        if (COND) {
+            if (a.rhs != nullptr && l < CBS) fT_l = a.rhs[(cell - a.first) * (size_t)CBS + l];
+            if (a.uF != nullptr && l < NF) uF_l = a.uF[(cell - a.first) * (size_t)NF + l];
+        }
 
         // ================= S0: geometry (every lane of the group, registers) ==========
         PA_MARK("S0");
@@ -1257,6 +1289,9 @@ __global__ __launch_bounds__(64, (SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hh
             constexpr int NPAIRS = NTL * (NTL + 1) / 2;
             typedef double v4d __attribute__((ext_vector_type(4)));
             const int kk = lane >> 4, jj = lane & 15;
+            constexpr bool DIRECT = C::DIRECT_STORE && !COND;      // condensed mode: always through the LDS image
+            constexpr int OS = COND ? C::LDI : MS;                 // stride of the image
+            const bool want_image = COND || a.lc != nullptr;
             // no barrier is needed between the cells: the wavefront reads a cell's Z and then overwrites
             // it with the same cell's output image in program order
             wave_sync();      // Z complete (all columns written)
@@ -1308,7 +1343,7 @@ __global__ __launch_bounds__(64, (SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hh
                 }
                 PA_TICK(6 + 2 * (gi & 1));
                 PA_MARK("S8m");
-                if (C::DIRECT_STORE) {
+                if (DIRECT) {
                     // ---- S8 (lc only): straight from the accumulators to HBM, no LDS image.  lc is symmetric:
                     // the lane's D[row][col] is written at (col, row), where the 16 lanes of a group
                     // (jj = 0..15) cover 16 consecutive rows of one column = one 128-byte run; the second copy
@@ -1336,7 +1371,7 @@ __global__ __launch_bounds__(64, (SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hh
                             }
                     }
                 } else {
-                if (a.lc != nullptr && !(a.ablate & 128u)) {
+                if (want_image && !(a.ablate & 128u)) {
                     int t = 0;
 #pragma unroll
                     for (int I = 0; I < NTL; ++I)
@@ -1349,8 +1384,8 @@ __global__ __launch_bounds__(64, (SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hh
                                     const int row = 16 * I + kk + 4 * r;
                                     if (16 * I + 4 * r < MS && (16 * I + 4 * r + 3 < MS || row < MS)) {
                                         const double v = acc[t][r];
-                                        Og[row + colj * MS] = v;
-                                        if (I != J) Og[colj + row * MS] = v;
+                                        Og[row + colj * OS] = v;
+                                        if (I != J) Og[colj + row * OS] = v;
                                     }
                                 }
                             }
@@ -1359,19 +1394,99 @@ __global__ __launch_bounds__(64, (SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hh
                 }
                 PA_TICK(7 + 2 * (gi & 1));
             }
-            if (C::CORNER_VALU && a.lc != nullptr && !(a.ablate & 128u) && l < C::NCORNER * (C::NCORNER + 1) / 2) {
-                if (C::DIRECT_STORE) {
+            if (C::CORNER_VALU && want_image && !(a.ablate & 128u) && l < C::NCORNER * (C::NCORNER + 1) / 2) {
+                if (DIRECT) {
                     if (valid) {
                         double *o = a.lc + (cell - a.first) * (size_t)(MS * MS);
                         o[(16 + cic) + (16 + cjc) * MS] = corner;
                         o[(16 + cjc) + (16 + cic) * MS] = corner;
                     }
                 } else {
-                    S[C::oOUT + (16 + cic) + (16 + cjc) * MS] = corner;
-                    S[C::oOUT + (16 + cjc) + (16 + cic) * MS] = corner;
+                    S[C::oOUT + (16 + cic) + (16 + cjc) * OS] = corner;
+                    S[C::oOUT + (16 + cjc) + (16 + cic) * OS] = corner;
                 }
             }
-            if (C::DIRECT_STORE) {
+            if (COND) {
+                // ================= S9 (condensed mode): eliminate the cell unknowns in the LDS image ==================
+                // Row i of the symmetric (MS + 1) x (MS + 1) matrix  M = [A_TT A_TF f_T; A_FT A_FF 0; f_T^T 0 0]  belongs to
+                // lane i.  The first CBS steps of its Cholesky factorization, row by row (left-looking, Eigen's LLT order on
+                // A_TT), leave  L_TT = chol(A_TT)  in the cell rows,  W^T = A_FT L_TT^-T  in the face rows and
+                // w0^T = f_T^T L_TT^-T  in the last one -- the forward substitutions ride on the factorization's chain --
+                // and the Schur complement of the pivots is what is asked for:
+                //   S = A_FF - W^T W,   g = -W^T w0,   uT = L_TT^-T (w0 - W uF).
+                PA_MARK("S9");
+                constexpr int LDI = C::LDI, NPV = CBS;
+                double *A = S + C::oOUT;
+                if (l < CBS) A[MS * LDI + l] = fT_l;                            // row MS: f_T
+                if (a.uF != nullptr && l < NF) A[MS * LDI + CBS + l] = uF_l;       // (behind it: the face unknowns)
+                wave_sync();
+                const int i = l <= MS ? l : 0;                                  // (lanes beyond the last row mirror row 0)
+                double row[NPV];
+#pragma unroll
+                for (int k = 0; k + 1 < NPV; k += 2) {
+                    const double2 v = lds_pair(A + i * LDI + k);
+                    row[k] = v.x; row[k + 1] = v.y;
+                }
+                if (NPV & 1) row[NPV - 1] = A[i * LDI + NPV - 1];
+                int badc = 0;
+                if (!(a.ablate & 256u)) {
+#pragma unroll
+                for (int j = 0; j < NPV; ++j) {
+                    // M[i][j] - sum_{k<j} L[i][k] L[j][k]; row j's prefix is in LDS already
+                    const double s = j == 0 ? row[0] : lds_dotsub_n(row[j], A + j * LDI, row, j);
+                    const double d = group_broadcast<G>(s, j);
+                    if (!(d > 0.0) && !badc) badc = j + 1;
+                    const double r = fast_rsqrt<1>(d);
+                    row[j] = s * r;
+                    if (l <= MS && l >= j) A[i * LDI + j] = (l == j) ? r : row[j];      // the diagonal holds 1 / L[j][j]
+                    wave_sync();
+                }
+                }
+                if (badc && !bad) bad = 200 + badc;
+                if (a.uF == nullptr) {
+                    // Schur complement, row i' = l - CBS of it by lane l: entries (m', i'), m' <= i', are the run
+                    // i'(i'+1)/2 .. of the column-packed upper triangle
+                    double *stg = S + C::oOUT + C::oSTG;
+                    const int ip = l - CBS;
+                    const bool frow = l >= CBS && l < MS;
+                    if (!(a.ablate & 512u)) {
+#pragma unroll
+                    for (int mp = 0; mp < NF; ++mp) {
+                        const double s = lds_dotsub<NPV>(A[i * LDI + CBS + mp], A + (CBS + mp) * LDI, row);
+                        if (frow && mp <= ip) stg[ip * (ip + 1) / 2 + mp] = s;
+                    }
+                    const double gi = lds_dotsub<NPV>(0.0, A + MS * LDI, row);
+                    if (frow) stg[C::NSP + ip] = gi;
+                    }
+                    wave_sync();
+                    if (valid && a.cond != nullptr) {
+                        double *o = a.cond + (cell - a.first) * (size_t)C::NCOND;
+                        static_assert(C::NCOND % 2 == 0, "16-byte stores of the packed record");
+#pragma unroll
+                        for (int e0 = 0; e0 < C::NCOND / 2; e0 += G) {
+                            const int e = e0 + l;
+                            if (e < C::NCOND / 2)
+                                *reinterpret_cast<double2 *>(o + 2 * e) = *reinterpret_cast<const double2 *>(stg + 2 * e);
+                        }
+                    }
+                } else {
+                    // recovery: t = w0 - W uF (lane k < CBS: column k of the face rows), then L_TT^T uT = t column by column
+                    double t = 0.0;
+                    const int k = l < CBS ? l : 0;
+                    t = A[MS * LDI + k];
+#pragma unroll
+                    for (int ip = 0; ip < NF; ++ip) t = __builtin_fma(-A[(CBS + ip) * LDI + k], A[MS * LDI + CBS + ip], t);
+                    const double rdk = A[k * LDI + k];
+#pragma unroll
+                    for (int m = NPV - 1; m >= 0; --m) {
+                        const double um = group_broadcast<G>(t * rdk, m);
+                        if (l == m) t = um;
+                        else if (l < m) t = __builtin_fma(-A[m * LDI + k], um, t);
+                    }
+                    if (valid && a.uT != nullptr && l < CBS) a.uT[(cell - a.first) * (size_t)CBS + l] = t;
+                }
+                wave_sync();      // the next cell's tables overwrite the image
+            } else if (DIRECT) {
                 wave_sync();      // the next cell's tables overwrite Z
             } else {
                 if (a.lc != nullptr && !(a.ablate & 128u)) {

@@ -9,16 +9,25 @@
 #define PA_STR2(x) #x
 #define PA_STR(x) PA_STR2(x)
 #define PA_CAT5(a, b, c, d, e) pa_entries_##a##_##b##_##c
-#define PA_ENTRY(STAB, G)                                                                          \
-    {PA_CD, PA_FD, PA_QUAD, STAB, G, &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, false>, \
-     &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, true>,                           \
-     (const void *)&pa::hho_local_ops_kernel<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, false>,        \
+#define PA_COND_NONE nullptr, nullptr, 0, nullptr
+// (the condensed mode needs a lane per row of [lc f_T; f_T^T 0]: msize + 1 <= G)
+#define PA_COND_OF(STAB, G)                                                                         \
+    (pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::MS + 1 <= G)                                          \
+        ? &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, (pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::MS + 1 <= G ? G : 64), 1>, pa::MODE_COND> \
+        : nullptr,                                                                                  \
+    (const void *)&pa::hho_local_ops_kernel<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, (pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::MS + 1 <= G ? G : 64), 1>, pa::MODE_COND>, \
+    (int)(pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, (pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::MS + 1 <= G ? G : 64), 1>::LDS_DOUBLES * sizeof(double)), \
+    "hho_condensed_ops<cd=" PA_STR(PA_CD) ",fd=" PA_STR(PA_FD) ",quad=" PA_STR(PA_QUAD) ",stab=" #STAB ",G=" #G ">"
+#define PA_ENTRY(STAB, G, COND)                                                                    \
+    {PA_CD, PA_FD, PA_QUAD, STAB, G, &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, pa::MODE_LC>, \
+     &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, pa::MODE_SPLIT>,                 \
+     (const void *)&pa::hho_local_ops_kernel<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, pa::MODE_LC>,  \
      (int)(pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::LDS_DOUBLES * sizeof(double)),                  \
      "hho_local_ops<cd=" PA_STR(PA_CD) ",fd=" PA_STR(PA_FD) ",quad=" PA_STR(PA_QUAD) ",stab=" #STAB ",G=" #G ">",                \
      pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::WAVES,                                                \
      pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::USE_PRE ? &pa::launch_pre<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>> : nullptr, \
-     pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::Pre::NPRE}
-#define PA_ENTRIES_G(G) PA_ENTRY(0, G), PA_ENTRY(1, G), PA_ENTRY(2, G)
+     pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::Pre::NPRE, COND}
+#define PA_ENTRIES_G(G) PA_ENTRY(0, G, PA_COND_NONE), PA_ENTRY(1, G, PA_COND_OF(1, G)), PA_ENTRY(2, G, PA_COND_OF(2, G))
 
 static const pa::KernelEntry k_entries[] = {
 #if PA_GMIN <= 16

@@ -19,12 +19,17 @@ struct KernelEntry {
     int waves_per_simd;        // the occupancy the instance is tuned for (Cfg::WAVES): the grid does not exceed it
     pre_launcher launch_pre;   // the one-thread-per-cell pre-pass the kernel consumes (nullptr: all-in-one kernel)
     int pre_doubles;           // doubles per cell of its record (Cfg::Pre::NPRE)
+    // condensed mode (static condensation fused behind the product; nullptr without a stabilization: A_TT singular)
+    local_ops_launcher launch_cond;
+    const void *func_cond;
+    int lds_bytes_cond;
+    const char *name_cond;
 };
 
-template <class C, bool SPLIT>
+template <class C, int MODE>
 hipError_t launch_local_ops(const LocalOpsArgs &a, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((hho_local_ops_kernel<C, SPLIT>), dim3(grid), dim3(64), C::LDS_DOUBLES * sizeof(double), s, a);
+    hipLaunchKernelGGL((hho_local_ops_kernel<C, MODE>), dim3(grid), dim3(64), C::LDS_DOUBLES * sizeof(double), s, a);
     return hipGetLastError();
 }
 
