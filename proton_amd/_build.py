@@ -14,8 +14,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ_DIR = os.path.join(HERE, "lib", "obj")
-LIB_PATH = os.path.join(HERE, "lib", "libproton_amd.so")
+# PA_BUILD_TAG=<name>: an A/B tuning build with its own objects and library (lib/variants/<name>/), selected at run time
+# with PA_LIB; the shipped library is never built from a tagged tree
+_TAG = os.environ.get("PA_BUILD_TAG")
+_OUT = os.path.join(HERE, "lib", "variants", _TAG) if _TAG else os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(_OUT, "obj")
+LIB_PATH = os.path.join(_OUT, "libproton_amd.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("PA_EXTRA_FLAGS"):        # experiments: extra compiler flags, e.g. "-mllvm -amdgpu-use-amdgpu-trackers"
@@ -61,12 +65,30 @@ def _deps_mtime():
     return max(os.path.getmtime(d) for d in deps)
 
 
+def _stamp(defs):
+    """the flag set an object was compiled with, kept next to it: an object built under PA_EXTRA_FLAGS / PA_WAVES_PER_EU
+    (tuning) is stale for a default build even when its mtime is recent"""
+    return " ".join(FLAGS + defs)
+
+
+def _stale(obj, defs, newest):
+    if not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+        return True
+    try:
+        with open(obj + ".flags") as f:
+            return f.read() != _stamp(defs)
+    except OSError:
+        return True
+
+
 def _compile(job):
     src, obj, defs = job
     cmd = [hipcc()] + FLAGS + defs + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+    with open(obj + ".flags", "w") as f:
+        f.write(_stamp(defs))
     return obj
 
 
@@ -77,15 +99,15 @@ def build(force=False, verbose=False, jobs=None):
     for (cd, fd, q, gmin) in configs():
         obj = os.path.join(OBJ_DIR, "inst_%d_%d_%d.o" % (cd, fd, q))
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-            todo.append((os.path.join(CSRC, "hho_inst.hip"), obj,
-                         ["-DPA_CD=%d" % cd, "-DPA_FD=%d" % fd, "-DPA_QUAD=%d" % q, "-DPA_GMIN=%d" % gmin] +
-                         ([] if os.environ.get("PA_WAVES_PER_EU") or os.environ.get("PA_EXTRA_FLAGS")
-                          else PER_CONFIG_FLAGS.get((cd, fd, q), []))))
+        defs = ["-DPA_CD=%d" % cd, "-DPA_FD=%d" % fd, "-DPA_QUAD=%d" % q, "-DPA_GMIN=%d" % gmin] + \
+            ([] if os.environ.get("PA_WAVES_PER_EU") or os.environ.get("PA_NO_PER_CONFIG_FLAGS")
+             else PER_CONFIG_FLAGS.get((cd, fd, q), []))
+        if force or _stale(obj, defs, newest):
+            todo.append((os.path.join(CSRC, "hho_inst.hip"), obj, defs))
     for unit in ("capi", "csr", "solver", "condensed"):
         unit_obj = os.path.join(OBJ_DIR, unit + ".o")
         objs.append(unit_obj)
-        if force or not os.path.exists(unit_obj) or os.path.getmtime(unit_obj) < newest:
+        if force or _stale(unit_obj, [], newest):
             todo.append((os.path.join(CSRC, unit + ".hip"), unit_obj, []))
     if todo:
         if verbose:

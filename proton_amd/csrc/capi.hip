@@ -683,7 +683,8 @@ static int select_kernel(pa_context *ctx, pa_degree_info di, int quad_kind, int 
         per_cu = 1;
     // A persistent grid of exactly waves_per_simd x 4 blocks per CU: when the compiler needs fewer registers than
     // the launch bound allows the hardware could hold more, and more was measured to be slower (msize 9: +24 %)
-    if (per_cu > 4 * e->waves_per_simd) per_cu = 4 * e->waves_per_simd;
+    const int waves = cond ? e->waves_per_simd_cond : e->waves_per_simd;
+    if (per_cu > 4 * waves) per_cu = 4 * waves;
     if (const char *env = std::getenv("PA_BLOCKS_PER_CU")) {
         const int v = std::atoi(env);
         if (v > 0) per_cu = v;

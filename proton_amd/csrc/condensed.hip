@@ -9,7 +9,8 @@
 //   * the same matrix built DIRECTLY in CSR from the mesh's face adjacency -- no triplets, no sort: a face's rows hold
 //     the unknowns of the (at most 7) non-Dirichlet faces of its (at most 2) cells, in ascending order of their
 //     compressed ids; a symbolic phase (once per mesh) records per face which local faces of which cell those are, and
-//     the numeric phase is a pure gather with every CSR entry written once, coalesced.
+//     the numeric phase is a pure gather: one thread per CSR entry, every entry written once, consecutive threads
+//     writing consecutive entries.
 // Row partition for the multi-GPU path: a slab owns the faces of its cell rows' blocks (bottom and vertical faces
 // of every cell row); the bottom faces of a slab with a slab below also take the contribution of that slab's top
 // cells, which arrives as fbs packed rows per cell (condensed_halo_pack_kernel) -- the whole exchange of a step.
@@ -155,39 +156,39 @@ __device__ __forceinline__ double cond_rhs_contrib(const CondMesh &m, const doub
     return s;
 }
 
-// numeric phase: one thread per (owned face q, column slot s, row k): the fbs entries (k, s, 0..fbs-1); slot 0 also
-// forms the right-hand side of row (q, k)
+// numeric phase: one thread per CSR entry of a face's rows -- (row k, column slot s, column k') with k' fastest, so
+// that consecutive threads write consecutive entries; 7 fbs^2 threads per owned face, the tail idle where a face has
+// fewer than 7 column faces.  The thread of (k, 0, 0) also forms the right-hand side of row (q, k).
 __global__ __launch_bounds__(256) void cond_fill_kernel(CondMesh m, uint32_t nown, int fbs, const CondFace *faces, const uint32_t *prefix,
                                                         const double *cond, const double *g, const double *halo,
                                                         double *values, double *rhs)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t per_face = (size_t)7 * fbs;
+    const uint32_t per_face = 7u * fbs * fbs;
     const uint32_t q = (uint32_t)(t / per_face);
     if (q >= nown) return;
-    const int s = (int)((t % per_face) / fbs), k = (int)(t % fbs);
+    const uint32_t e = (uint32_t)(t % per_face);
     const CondFace &r = faces[q];
-    if (s >= r.ncol) return;
+    const uint32_t rowlen = (uint32_t)r.ncol * fbs;
+    if (e >= rowlen * fbs) return;
+    const int k = (int)(e / rowlen), s = (int)((e % rowlen) / fbs), kp = (int)(e % fbs);
     const int nf = 4 * fbs, ncond = nf * (nf + 1) / 2 + nf, hd = fbs * (nf + 1);
     const int rowA = (r.rows & 3) * fbs + k, rowB = ((r.rows >> 2) & 3) * fbs + k;
     const uint8_t code = r.code[s];
     const double *recA = r.cA >= 0 ? cond + (size_t)r.cA * ncond : nullptr;
     const double *recB = r.cB >= 0 ? cond + (size_t)r.cB * ncond : nullptr;
     const double *hA = r.cA <= -2 ? halo + (size_t)(-2 - r.cA) * hd : nullptr;
-    double *out = values + ((size_t)prefix[q] * fbs * fbs + (size_t)k * fbs * r.ncol + (size_t)s * fbs);
-    for (int kp = 0; kp < fbs; ++kp) {
-        double v = 0.0;
-        if (code & 4) {
-            const int col = (code & 3) * fbs + kp;
-            v = recA ? cond_S(recA, rowA, col) : hA[k * nf + col];
-        }
-        if (code & 32) {
-            const double w = cond_S(recB, rowB, ((code >> 3) & 3) * fbs + kp);
-            v = (code & 4) ? v + w : w;
-        }
-        out[kp] = v;
+    double v = 0.0;
+    if (code & 4) {
+        const int col = (code & 3) * fbs + kp;
+        v = recA ? cond_S(recA, rowA, col) : hA[k * nf + col];
     }
-    if (s == 0 && rhs != nullptr) {
+    if (code & 32) {
+        const double w = cond_S(recB, rowB, ((code >> 3) & 3) * fbs + kp);
+        v = (code & 4) ? v + w : w;
+    }
+    values[(size_t)prefix[q] * fbs * fbs + e] = v;
+    if (s == 0 && kp == 0 && rhs != nullptr) {
         double b = 0.0;
         bool have = false;
         if (r.cA >= 0) { b = cond_rhs_contrib(m, recA, r.cA, rowA, fbs, g); have = true; }
@@ -315,7 +316,7 @@ hipError_t cond_fill(hipStream_t stream, const CondMesh &m, uint32_t nown, int f
                      const double *cond, const double *g, const double *halo, double *values, double *rhs)
 {
     if (nown == 0) return hipSuccess;
-    hipLaunchKernelGGL(cond_fill_kernel, dim3(blocks_for((size_t)nown * 7 * fbs)), dim3(256), 0, stream, m, nown, fbs, faces, prefix,
+    hipLaunchKernelGGL(cond_fill_kernel, dim3(blocks_for((size_t)nown * 7 * fbs * fbs)), dim3(256), 0, stream, m, nown, fbs, faces, prefix,
                        cond, g, halo, values, rhs);
     return hipGetLastError();
 }

@@ -45,6 +45,10 @@
 #endif
 // 1: the per-cell head (geometry, cell quadrature, moments, stiffness, Cholesky of gr_lhs) comes from the
 // one-thread-per-cell pre-pass of hho_pre.hpp; 0: the cooperative kernel computes it itself (A/B builds)
+// the same for the condensed-mode instance (0 = as the local-operator kernel)
+#ifndef PA_COND_WAVES_PER_EU
+#define PA_COND_WAVES_PER_EU 0
+#endif
 #ifndef PA_USE_PRE
 #define PA_USE_PRE 1
 #endif
@@ -77,6 +81,14 @@
 // blocks of one XCD (blockIdx mod 8) take consecutive cells
 #ifndef PA_XCD_MAP
 #define PA_XCD_MAP 1
+#endif
+// condensed mode: pivots per LDS round trip of the partial factorization (1 = the unblocked chain)
+#ifndef PA_COND_NB
+#define PA_COND_NB 1
+#endif
+// condensed mode: face count from which the Schur complement A_FF - W^T W is formed on the matrix pipe
+#ifndef PA_COND_SCHUR_MFMA_MIN
+#define PA_COND_SCHUR_MFMA_MIN 12
 #endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
@@ -160,9 +172,10 @@ struct Cfg {
     // without spills beat 3 with), the others fit 3 waves/SIMD
     // (the dense fancy form carries the mass factor and the dense T_F as well: one step lower, or it spills by the hundred)
     static constexpr bool DENSE_FANCY = STAB_ == STAB_FANCY && CD_ != FD_ + 1;
-    static constexpr int WAVES = PA_WAVES_PER_EU ? PA_WAVES_PER_EU
+    static constexpr int WAVES_LC = PA_WAVES_PER_EU ? PA_WAVES_PER_EU
                                  : DENSE_FANCY ? ((MS > 24 || RBS > 10) ? 1 : (MS > 16 || RBS > 6) ? 2 : 3)
                                                : ((MS > 24 || RBS > 10) ? 2 : 3);
+    static constexpr int WAVES = (COND_ != 0 && PA_COND_WAVES_PER_EU) ? PA_COND_WAVES_PER_EU : WAVES_LC;
     static constexpr bool HAS_STAB = STAB != STAB_NONE;
     // lc-only path: accumulators -> HBM directly (no LDS image) where the matrix is big enough for the
     // 128-byte runs to pay (measured: -5 % at msize 14, -2 % at 22, -1 % at 31, but +19 % at msize 9)
@@ -212,14 +225,16 @@ struct Cfg {
     static_assert(USE_PRE || SPC <= 1 || CBS * NRP <= 2 * NQ * NPW, "GRC must fit the dead quadrature tables");
     static constexpr int oZ = 0;                              // ZS x MS    (written from S5 on)
     static constexpr int oOUT = 0;                            // MS x MS    (written in S8, after the last read of Z)
-    // condensed mode: image of the symmetric matrix [lc f_T; f_T^T 0], row-major == column-major, even stride LDI;
-    // the packed result (upper triangle of S, then g) is staged on the rows of the cell block once they are dead, or
-    // behind the image where that block is too small (cbs <= 3)
-    static constexpr int LDI = (CBS + 4 * FBS + 2) & ~1;
+    // condensed mode: image of the symmetric matrix [lc f_T; f_T^T 0], MS + 1 rows, row-major == column-major; stride
+    // LDI even (16-byte rows) with LDI / 2 odd (the row-per-lane reads touch every bank once).  It lies over regions Q
+    // AND P: nothing of P is needed after S6, and the condensed mode deposits the next cell's record only after S9.
+    // The packed result (upper triangle of S, then g) is staged on the rows of the cell block once they are dead, or
+    // behind the image where that block is too small (cbs <= 3).
+    static constexpr int LDI = ((MS + 1) & ~1) % 4 == 2 ? ((MS + 1) & ~1) : ((MS + 1) & ~1) + 2;
     static constexpr int NSP = NF * (NF + 1) / 2, NCOND = NSP + NF;
     static constexpr int oSTG = CBS * LDI >= NCOND ? 0 : (MS + 1) * LDI;
-    static constexpr int condQ = (MS + 1) * LDI + (CBS * LDI >= NCOND ? 0 : NCOND);
-    static constexpr int sizeQ = imax(imax(endQ, ZS * MS), COND ? condQ : MS * MS);
+    static constexpr int condNeed = (MS + 1) * LDI + (CBS * LDI >= NCOND ? 0 : NCOND);
+    static constexpr int sizeQ = imax(imax(endQ, ZS * MS), MS * MS);
     // region P: lives until the forward substitutions are done.  Stiffness, stride LD; its [1:,1:]
     // block becomes chol(gr_lhs) row by row: oST is odd so that the block (and every row of it)
     // starts on a 16-byte boundary
@@ -243,7 +258,8 @@ struct Cfg {
     static constexpr int oMCRl = oMCl + CBS * LDM;
     static constexpr int oFTp = (oMCRl + CBS + 1) & ~1;
     static constexpr int oFT = USE_PRE ? oFTp : oFTo;
-    static constexpr int LDS_PER_CELL = (USE_PRE && GENERAL_FANCY) ? ((oFTp + NF * RBS + 1) & ~1) : ((oDUMMY + 4 + 1) & ~1);
+    static constexpr int LDS_BASE = (USE_PRE && GENERAL_FANCY) ? ((oFTp + NF * RBS + 1) & ~1) : ((oDUMMY + 4 + 1) & ~1);
+    static constexpr int LDS_PER_CELL = COND ? imax(LDS_BASE, (condNeed + 1) & ~1) : LDS_BASE;
     static constexpr int LDS_DOUBLES = CPW * LDS_PER_CELL;
 };
 
@@ -497,6 +513,90 @@ __device__ __forceinline__ int lds_cholesky_blocked(double *A, int l)
             }
         }
         // column block to LDS: L below the diagonal, 1/L[j][j] on it
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+            if (c < nb && act && l >= j0 + c) A[i * LD + j0 + c] = (l == j0 + c) ? rd[c] : row[j0 + c];
+        wave_sync();
+    }
+    return bad;
+}
+
+// -------------------------------------------------------------------------------------
+// The first NPV steps of the Cholesky factorization of a symmetric NROWS x NROWS matrix (NROWS >= NPV), one lane per
+// row, NB pivots per LDS round trip -- the condensed mode's elimination of the cell unknowns.  Lane i holds the first
+// NPV entries of row i in `row` and leaves L[i][0..NPV) there; the rows in LDS (row-major, stride LD) receive the same,
+// with 1 / L[j][j] on the diagonal.  Per block J = j0 .. j0+nb-1 every lane forms, from the LDS rows of J,
+//   D = M[J,J] - L[J,:j0] L[J,:j0]^T   (redundantly: it is the pivot block every lane needs)  and
+//   t = M[i,J] - L[i,:j0] L[J,:j0]^T   (its own row),
+// factors D in registers and solves its row against it: one round trip per block instead of one per pivot.
+// Returns 0 or 1 + index of the first non-positive pivot.
+// -------------------------------------------------------------------------------------
+template <int NPV, int NROWS, int NB, int LD>
+__device__ __forceinline__ int lds_partial_cholesky(double *A, int l, double (&row)[NPV])
+{
+    const bool act = l < NROWS;
+    const int i = act ? l : 0;
+    int bad = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < NPV; j0 += NB) {
+        const int nb = (NPV - j0 < NB) ? (NPV - j0) : NB;       // constant after unrolling
+        double d[NB][NB], t[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            if (r < nb) {
+                t[r] = row[j0 + r];
+#pragma unroll
+                for (int c = 0; c <= r; ++c) d[r][c] = A[(j0 + r) * LD + j0 + c];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < j0; k += 2) {                    // rows of J, two columns per 16-byte read
+            const bool two = k + 1 < j0;
+            double lj[NB], lj1[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                if (r < nb) {
+                    if (two) { const double2 v = lds_pair(A + (j0 + r) * LD + k); lj[r] = v.x; lj1[r] = v.y; }
+                    else { lj[r] = A[(j0 + r) * LD + k]; lj1[r] = 0.0; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                if (r < nb) {
+                    t[r] = __builtin_fma(-row[k], lj[r], t[r]);
+                    if (two) t[r] = __builtin_fma(-row[k + 1], lj1[r], t[r]);
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) {
+                        d[r][c] = __builtin_fma(-lj[r], lj[c], d[r][c]);
+                        if (two) d[r][c] = __builtin_fma(-lj1[r], lj1[c], d[r][c]);
+                    }
+                }
+            }
+        }
+        double rd[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            if (c < nb) {
+                double p = d[c][c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) p = __builtin_fma(-d[c][k], d[c][k], p);
+                if (!(p > 0.0) && !bad) bad = j0 + c + 1;
+                rd[c] = fast_rsqrt<1>(p);
+#pragma unroll
+                for (int r = c + 1; r < NB; ++r) {
+                    if (r < nb) {
+                        double q = d[r][c];
+#pragma unroll
+                        for (int k = 0; k < c; ++k) q = __builtin_fma(-d[r][k], d[c][k], q);
+                        d[r][c] = q * rd[c];                    // Ld[r][c]
+                    }
+                }
+                double x = t[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) x = __builtin_fma(-row[j0 + k], d[c][k], x);
+                row[j0 + c] = x * rd[c];                        // L[i][j0 + c] (for i in J, i > j0 + c: == Ld; i == j0 + c: L[j][j])
+            }
+        }
 #pragma unroll
         for (int c = 0; c < NB; ++c)
             if (c < nb && act && l >= j0 + c) A[i * LD + j0 + c] = (l == j0 + c) ? rd[c] : row[j0 + c];
@@ -770,13 +870,6 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         asm volatile("" : "+v"(l));
         const bool valid = base + g < a.n;
         const size_t cell = a.first + (valid ? base + g : a.n - 1);
-        // condensed mode: the cell's right-hand side (lanes < CBS) and, for the recovery, its face unknowns (lanes < NF),
-        // one value per lane, in flight until the image phase
-        double fT_l = 0.0, uF_l = 0.0;
-        if (COND) {
-            if (a.rhs != nullptr && l < CBS) fT_l = a.rhs[(cell - a.first) * (size_t)CBS + l];
-            if (a.uF != nullptr && l < NF) uF_l = a.uF[(cell - a.first) * (size_t)NF + l];
-        }
 
         // ================= S0: geometry (every lane of the group, registers) ==========
         PA_MARK("S0");
@@ -1273,7 +1366,16 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         }
         wave_sync();
         PA_TICK(4);
-        if (C::USE_PRE) rec_deposit();      // region P is free (L, reciprocals, scalars all consumed): next cell's record
+        // region P is free (L, reciprocals, scalars all consumed): next cell's record -- in the condensed mode only after
+        // S9, whose image lies over P as well
+        if (C::USE_PRE && !COND) rec_deposit();
+        // condensed mode: the cell's right-hand side (lanes < CBS) and, for the recovery, its face unknowns (lanes < NF),
+        // one value per lane, in flight during the product
+        double fT_l = 0.0, uF_l = 0.0;
+        if (COND) {
+            if (a.rhs != nullptr && l < CBS) fT_l = a.rhs[(cell - a.first) * (size_t)CBS + l];
+            if (a.uF != nullptr && l < NF) uF_l = a.uF[(cell - a.first) * (size_t)NF + l];
+        }
 
         // ================= S7/S8 (lc only): lc = Z^T Z on the matrix pipe ============
         // v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) B(4x16); lane l supplies A[l&15][l>>4] and
@@ -1429,7 +1531,9 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 }
                 if (NPV & 1) row[NPV - 1] = A[i * LDI + NPV - 1];
                 int badc = 0;
-                if (!(a.ablate & 256u)) {
+                if (PA_COND_NB > 1) {
+                    if (!(a.ablate & 256u)) badc = lds_partial_cholesky<NPV, MS + 1, PA_COND_NB, LDI>(A, l, row);
+                } else if (!(a.ablate & 256u)) {
 #pragma unroll
                 for (int j = 0; j < NPV; ++j) {
                     // M[i][j] - sum_{k<j} L[i][k] L[j][k]; row j's prefix is in LDS already
@@ -1449,7 +1553,43 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                     double *stg = S + C::oOUT + C::oSTG;
                     const int ip = l - CBS;
                     const bool frow = l >= CBS && l < MS;
-                    if (!(a.ablate & 512u)) {
+                    constexpr bool SCHUR_MFMA = NF >= PA_COND_SCHUR_MFMA_MIN && NF <= 16;
+                    if (a.ablate & 512u) {
+                    } else if (SCHUR_MFMA) {
+                        // W^T W on the matrix pipe, all 64 lanes on one cell at a time: W[k][j] = L[CBS + j][k] is both
+                        // operands of the one 16 x 16 tile (one LDS read per lane and k-step); the lane's P[kk + 4r][jj]
+                        // meets A_FF(kk + 4r, jj) of the image's lower triangle and goes to the packed upper one
+                        const double gi = lds_dotsub<NPV>(0.0, A + MS * LDI, row);
+#pragma unroll
+                        for (int gi_ = 0; gi_ < C::CPW; ++gi_) {
+                            const double *Ag = smem + gi_ * C::LDS_PER_CELL + C::oOUT;
+                            double *sg = smem + gi_ * C::LDS_PER_CELL + C::oOUT + C::oSTG;
+                            v4d p = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int ks = 0; ks < (NPV + 3) / 4; ++ks) {
+                                const int k = 4 * ks + kk;
+                                const bool ok = (4 * ks + 3 < NPV || k < NPV) && (NF == 16 || jj < NF);
+                                const double w = Ag[ok ? (CBS + jj) * LDI + k : 0];
+                                const double wz = ok ? w : 0.0;
+                                p = __builtin_amdgcn_mfma_f64_16x16x4f64(wz, wz, p, 0, 0, 0);
+                            }
+                            double aff[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int ir = kk + 4 * r;
+                                const bool up = ir <= jj && (NF == 16 || jj < NF);
+                                aff[r] = Ag[up ? (CBS + jj) * LDI + CBS + ir : 0];
+                            }
+                            // (the staging area lies on the cell rows: every read of W above has been issued, and LDS
+                            // operations of a wavefront execute in order)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int ir = kk + 4 * r;
+                                if (4 * r < NF && ir <= jj && (NF == 16 || jj < NF)) sg[jj * (jj + 1) / 2 + ir] = aff[r] - p[r];
+                            }
+                        }
+                        if (frow) stg[C::NSP + ip] = gi;
+                    } else {
 #pragma unroll
                     for (int mp = 0; mp < NF; ++mp) {
                         const double s = lds_dotsub<NPV>(A[i * LDI + CBS + mp], A + (CBS + mp) * LDI, row);
@@ -1485,7 +1625,8 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                     }
                     if (valid && a.uT != nullptr && l < CBS) a.uT[(cell - a.first) * (size_t)CBS + l] = t;
                 }
-                wave_sync();      // the next cell's tables overwrite the image
+                wave_sync();      // every read of the image is done
+                if (C::USE_PRE) { rec_deposit(); wave_sync(); }      // the next cell's record, into its place in region P
             } else if (DIRECT) {
                 wave_sync();      // the next cell's tables overwrite Z
             } else {

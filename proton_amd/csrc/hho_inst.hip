@@ -9,7 +9,7 @@
 #define PA_STR2(x) #x
 #define PA_STR(x) PA_STR2(x)
 #define PA_CAT5(a, b, c, d, e) pa_entries_##a##_##b##_##c
-#define PA_COND_NONE nullptr, nullptr, 0, nullptr
+#define PA_COND_NONE nullptr, nullptr, 0, nullptr, 0
 // (the condensed mode needs a lane per row of [lc f_T; f_T^T 0]: msize + 1 <= G)
 #define PA_COND_OF(STAB, G)                                                                         \
     (pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::MS + 1 <= G)                                          \
@@ -17,7 +17,8 @@
         : nullptr,                                                                                  \
     (const void *)&pa::hho_local_ops_kernel<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, (pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::MS + 1 <= G ? G : 64), 1>, pa::MODE_COND>, \
     (int)(pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, (pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::MS + 1 <= G ? G : 64), 1>::LDS_DOUBLES * sizeof(double)), \
-    "hho_condensed_ops<cd=" PA_STR(PA_CD) ",fd=" PA_STR(PA_FD) ",quad=" PA_STR(PA_QUAD) ",stab=" #STAB ",G=" #G ">"
+    "hho_condensed_ops<cd=" PA_STR(PA_CD) ",fd=" PA_STR(PA_FD) ",quad=" PA_STR(PA_QUAD) ",stab=" #STAB ",G=" #G ">", \
+    pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, (pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::MS + 1 <= G ? G : 64), 1>::WAVES
 #define PA_ENTRY(STAB, G, COND)                                                                    \
     {PA_CD, PA_FD, PA_QUAD, STAB, G, &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, pa::MODE_LC>, \
      &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, pa::MODE_SPLIT>,                 \

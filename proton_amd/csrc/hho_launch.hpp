@@ -24,6 +24,7 @@ struct KernelEntry {
     const void *func_cond;
     int lds_bytes_cond;
     const char *name_cond;
+    int waves_per_simd_cond;
 };
 
 template <class C, int MODE>
