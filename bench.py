@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- cells assembled per second on an N x N quad mesh (BASELINE.json's metric).
 
-A "step" is one pass of the hot path over the whole mesh: for every cell the local operator
-lc = data + stab (make_hho_laplacian + make_hho_fancy_stabilization, hho.hpp:32-237) and the
-cell right-hand side (make_rhs, utils.hpp:153-174) are computed and written to HBM
-(mode L of BASELINE.md section 4: 8 msize^2 + 8 cbs + 80 algorithmic bytes per cell).
-Default workload: the north-star target, 1024 x 1024, k = 2 (hho_degree_info(3, 2)), tensor
-Gauss, fancy stabilization.  Inputs (the structured mesh) are generated on the device and are
-resident in HBM when the timed region starts.
+A "step" is one pass of the hot path over the whole mesh, in one of two modes:
+
+  L  local operators to HBM (the mode of BASELINE.md section 4 the headline is quoted on): for every cell
+     lc = data + stab (make_hho_laplacian + stabilization, hho.hpp:32-237) and the cell right-hand side
+     (make_rhs, utils.hpp:153-174); 8 msize^2 + 8 cbs + 80 algorithmic bytes per cell.
+  C  condensed: cell right-hand sides, then the SAME local-operator pass with the static condensation fused behind it
+     (no lc in HBM: per cell the packed Schur complement + condensed rhs), then the face-only global system assembled
+     directly in CSR (values + right-hand side of the rows this rank owns); 16 (4 fbs)^2 + 8 (4 fbs) + 80 algorithmic
+     bytes per cell (mode C).
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-With N > 1 the cell rows are block-partitioned over the ranks (strong scaling, same mesh) and
-every step ends with the exchange the north star names: static condensation of the cell dofs and
-an RCCL all_gather of the condensed face-dof blocks (values only; indices are closed-form).
+Defaults: N = 1 -> the north-star target, 1024 x 1024, k = 2 (hho_degree_info(3, 2)), tensor Gauss, fancy stabilization,
+mode L.  N > 1 -> BASELINE.json's config 5, 2048 x 2048, k = 3, mode C, STRONG scaling: the cell rows are block-partitioned
+over the ranks, every rank assembles the CSR rows of the faces it owns, and the one exchange of a step is the packed
+top-face rows of each slab's top cell row, sent one slab up through the library's RCCL entry points (pa_comm_*).  The N > 1
+step is the N = 1 step of the same mode plus that exchange: `--gpus 1 --workload quad2048_k3 --mode C` runs exactly the
+N > 1 step minus the exchange, and every N > 1 line carries `same_step_one_gpu` (the whole mesh on rank 0's GPU alone,
+same mode, same code) so that the scaling of like with like can be read off one run.
 
+Inputs (the structured mesh) are generated on the device and are resident in HBM when the timed region starts.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -57,15 +64,26 @@ WORKLOADS = {
 BASELINE_METRIC = 'cells assembled/sec (+ achieved HBM GB/s) on N×N quad mesh, k=1..3'
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # 256 CU x 4 SIMD x 16 FMA/clk x 2 x 2.4 GHz; v_mfma_f64_16x16x4_f64 measured at 64 clk = the same rate
-# FP64 work of the REFERENCE's algorithm per cell (hand operation-count model, +-30 %)
-REFERENCE_FLOPS_PER_CELL = {(2, 1, "tensor", "fancy"): 16.7e3, (2, 1, "fan", "naive"): 14.7e3, (3, 2, "fan", "naive"): 60.5e3,
-                            (3, 2, "tensor", "fancy"): 67.1e3, (0, 1, "tensor", "fancy"): 9.1e3, (4, 3, "tensor", "fancy"): 197.5e3}
 
 
-def bytes_per_cell(msize, cbs):
-    """Algorithmic bytes per cell, mode L (BASELINE.md section 4 / SURVEY.md section 8d):
-    lc written (8 msize^2) + cell rhs written (8 cbs) + 4 node coordinates (64) + 4 u32 ids (16)."""
-    return 8 * msize * msize + 8 * cbs + 80
+def reference_flops_per_cell(w):
+    """EXACT FP64 operations per cell of the reference's algorithm (make_hho_laplacian + stabilization), counted by the
+    instrumented restatement oracle/flopcount (every double add / mul / div / sqrt of hho_oracle.c) and frozen in
+    oracle/flops_per_cell.json (tests/test_oracle_flops.py keeps the file honest)."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "oracle", "flops_per_cell.json")))["per_cell"]
+        return tab["%d,%d,%s,%s" % (w["cd"], w["fd"], w["quad"], w["stab"])]["local_ops_flops"]
+    except (OSError, KeyError):
+        return None
+
+
+def bytes_per_cell(mode, msize, cbs, fbs):
+    """Algorithmic bytes per cell (BASELINE.md section 4 / SURVEY.md section 8d).
+    L: lc written (8 msize^2) + cell rhs written (8 cbs) + 4 node coordinates (64) + 4 u32 ids (16).
+    C: condensed face-face COO, 16 B per entry (16 (4 fbs)^2) + condensed rhs (8 * 4 fbs) + the same 80 bytes read."""
+    if mode == "L":
+        return 8 * msize * msize + 8 * cbs + 80
+    return 16 * (4 * fbs) ** 2 + 8 * 4 * fbs + 80
 
 
 def cpu_baseline_cut(w, target_seconds=15.0):
@@ -121,32 +139,194 @@ def workload_mesh(w):
     return points, ptids
 
 
-def cpu_baseline(w, sample_rows, target_seconds=15.0):
-    """The oracle (CPU restatement, single thread like the reference) on a bounded sample of the
-    same workload: the first `sample_rows` cell rows of the same mesh (0 = as many rows as take
-    about `target_seconds` at the rate measured on a small probe)."""
+def cpu_baseline(w, sample_rows, target_seconds=6.0):
+    """The oracle (CPU restatement of the reference's loop; oracle/hho_oracle.c, -O3 -mavx like the reference's Release
+    build) on a bounded sample of the same workload: the first rows of the same mesh.  Two spans, each with one thread
+    (the reference is single-threaded: the reference-equivalent number, `value`) and with every host core (OpenMP over
+    cells): the per-cell operators + rhs alone, and the span the reference's drivers print as "Matrix assembly"
+    (cuthho_square.cpp:881-905, obstacle.cpp:145-161: make_assembler, operators, rhs, assemble, finalize)."""
+    import numpy as np
     import oracle_lib
     N = w["N"]
-    points, ptids = workload_mesh(w)
     di = oracle_lib.degrees(w["cd"], w["fd"])
     quad = oracle_lib.QUAD_TENSOR if w["quad"] == "tensor" else oracle_lib.QUAD_FAN
     stab = oracle_lib.STAB_FANCY if w["stab"] == "fancy" else oracle_lib.STAB_NAIVE
-    probe = min(N * N, 4096)
+    cores = oracle_lib.max_threads()
+    out = {"unit": "cells/s", "kind": "port", "cores": 1, "cores_all": cores}
+    if w.get("perturb"):
+        # general quadrilaterals: the oracle's assembly span works on the generator mesh; time the operators on the
+        # displaced mesh through the batch entry point
+        points, ptids = workload_mesh(w)
+        L = oracle_lib.lib()
+        ptids = np.ascontiguousarray(ptids, dtype=np.uint64)
+        fn = L.hho_builtin_fn(w["fn"])
+
+        def ops(n, nt):
+            lc = np.zeros((n, di.msize, di.msize)); rhs = np.zeros((n, di.cbs))
+            t0 = time.perf_counter()
+            st = L.hho_local_ops_batch_mt(oracle_lib._dp(points), oracle_lib._u64p(ptids), 0, n, di, quad, stab, fn, None, w["dinc"],
+                                          oracle_lib._dp(lc), oracle_lib._dp(rhs), nt)
+            assert st == 0
+            return n / (time.perf_counter() - t0)
+        rate = ops(min(N * N, 4096), 1)
+        rows = sample_rows if sample_rows > 0 else max(1, min(N, int(target_seconds * rate / N)))
+        out["value"] = ops(rows * N, 1)
+        out["value_all_cores"] = ops(min(N, rows * min(cores, 8)) * N, cores)
+        out["sample"] = "first %d of %d cell rows of the same (displaced) mesh, operators + rhs, oracle/hho_oracle.c" % (rows, N)
+        return out
+    probe = oracle_lib.matrix_assembly_timed(N, di, quad, stab, (0, max(1, 4096 // N)), w["fn"], 2, w["dinc"], w["lo"], w["hi"], 1)
+    rate = probe["cells"] / probe["seconds_assembly"]
+    rows = sample_rows if sample_rows > 0 else max(1, min(N, int(target_seconds * rate / N)))
+    one = oracle_lib.matrix_assembly_timed(N, di, quad, stab, (0, rows), w["fn"], 2, w["dinc"], w["lo"], w["hi"], 1)
+    rows_all = max(rows, min(N, rows * min(cores, 8)))
+    allc = oracle_lib.matrix_assembly_timed(N, di, quad, stab, (0, rows_all), w["fn"], 2, w["dinc"], w["lo"], w["hi"], cores)
+    out.update({
+        "value": one["cells"] / one["seconds_ops"],
+        "value_all_cores": allc["cells"] / allc["seconds_ops"],
+        "matrix_assembly": {"value": one["cells"] / one["seconds_assembly"], "value_all_cores": allc["cells"] / allc["seconds_assembly"],
+                            "unit": "cells/s",
+                            "what": "the span the reference prints as \"Matrix assembly\" (cuthho_square.cpp:881-905): make_assembler + "
+                                    "per-cell operators + rhs + assembler.assemble + finalize (setFromTriplets)"},
+        "sample": "first %d (1 thread) / %d (%d threads, OpenMP over cells) of %d cell rows of the same mesh: %.1f + %.1f s and %.1f + %.1f s; "
+                  "`value` = per-cell operators + rhs, one thread (the reference is single-threaded); oracle/hho_oracle.c, gcc -O3 -mavx"
+                  % (rows, rows_all, cores, N, one["seconds_ops"], one["seconds_assembly"], allc["seconds_ops"], allc["seconds_assembly"]),
+    })
+    return out
+
+
+class Pipeline:
+    """The step of one rank: its slab of the mesh, its buffers, the sequence of library calls of one pass."""
+
+    def __init__(self, torch, pa, w, mode, rows, N, device_index, comm=None, host_exchange=None):
+        from proton_amd.batch import BatchAssembler
+        self.torch, self.pa, self.w, self.mode, self.N = torch, pa, w, mode, N
+        self.quad = pa.QUAD_TENSOR if w["quad"] == "tensor" else pa.QUAD_FAN
+        self.stab = pa.STAB_FANCY if w["stab"] == "fancy" else pa.STAB_NAIVE
+        self.di, _ = pa.degree_info(w["cd"], w["fd"])
+        self.sz = pa.sizes_for(self.di, self.quad)
+        self.asm = BatchAssembler(device_index)
+        self.comm, self.host_exchange = comm, host_exchange
+        asm, sz, dev = self.asm, self.sz, self.asm.device
+        self.cut = bool(w.get("cut"))
+        if self.cut:
+            asm.cut_preprocess(N, refsteps=4)                    # host preprocessing: outside the timed region
+            # (side-stream overlap of the cut cells' kernel, pa_context_set_cut_overlap: measured SLOWER here, 0.75 vs 0.69 ms
+            # per step -- the persistent grid of the uncut cells' kernel holds the whole chip, the two only contend)
+            asm.ctx.set_cut_overlap(bool(os.environ.get("PA_CUT_OVERLAP")))
+        elif w.get("perturb"):
+            self.mesh_keep = general_quad_mesh(torch, N, w["lo"], w["hi"], w["perturb"], dev)     # caller-owned device arrays
+            asm.ctx.mesh_attach_device(self.mesh_keep[0].data_ptr(), (N + 1) * (N + 1), self.mesh_keep[1].data_ptr(), N * N)
+        else:
+            asm.generate_mesh(N, N, w["lo"], w["hi"], rows=rows)
+        self.n = asm.ncells
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.rhs = torch.empty((self.n, sz.cbs), **f64)
+        if mode == "L":
+            self.lc = torch.empty((self.n, sz.msize, sz.msize), **f64)
+            if self.cut:
+                self.cut_lc = torch.empty((max(asm.ncut, 1), sz.msize, sz.msize), **f64)
+                self.cut_rhs = torch.empty((max(asm.ncut, 1), sz.cbs), **f64)
+        else:
+            ci = self.ci = asm.ctx.condensed_query(self.di)
+            self.rec = torch.empty((self.n, ci.cond_doubles), **f64)
+            self.g = asm.dirichlet_data(w["fd"], 2)                       # boundary data: sin(pi x) sin(pi y) (setup)
+            self.rowptr, self.colind = asm.condensed_csr_pattern(w["cd"], w["fd"])          # symbolic phase (setup)
+            self.values = torch.empty(max(ci.nnz_owned, 1), **f64)
+            self.b = torch.empty(max(ci.row_end - ci.row_begin, 1), **f64)
+            self.halo_out = torch.empty((max(ci.halo_cells, 1), ci.halo_doubles), **f64)
+            self.halo_in = torch.zeros((N, ci.halo_doubles), **f64) if ci.has_below else None
+        self.ev = {}
+
+    def _tick(self, i, name):
+        if i is not None:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.ev.setdefault(i, []).append((name, e))
+
+    def step(self, i=None):
+        pa, asm, w, di, n = self.pa, self.asm, self.w, self.di, self.n
+        if self.mode == "L":
+            if self.cut and asm.ncut:
+                asm.ctx.cut_local_ops(w["fd"], asm.level_set, pa.capi.LOC_NEGATIVE, w["fn"], 2, None, None, None,
+                                      self.cut_lc.data_ptr(), self.cut_rhs.data_ptr(), None)
+            self._tick(i, "start")
+            asm.ctx.local_ops(di, self.quad, self.stab, 0, n, None, None, None, self.lc.data_ptr(), None)
+            self._tick(i, "ops")
+            asm.ctx.cell_rhs(w["cd"], w["dinc"], self.quad, w["fn"], 0, n, self.rhs.data_ptr(), None)
+            self._tick(i, "rhs")
+            if self.cut and asm.ncut:
+                asm.ctx.cut_merge(w["fd"], pa.capi.LOC_NEGATIVE, self.cut_lc.data_ptr(), self.cut_rhs.data_ptr(), self.lc.data_ptr(),
+                                  self.rhs.data_ptr())
+            return
+        ci, N = self.ci, self.N
+        self._tick(i, "start")
+        asm.ctx.cell_rhs(w["cd"], w["dinc"], self.quad, w["fn"], 0, n, self.rhs.data_ptr(), None)
+        self._tick(i, "rhs")
+        top = N if ci.halo_cells else 0
+        nd = ci.cond_doubles
+        if top:
+            # the slab's top cell row first: its packed top-face rows travel one slab up while the rest is computed
+            f0 = n - top
+            asm.ctx.condensed_ops(di, self.quad, self.stab, f0, top, self.rhs[f0:].data_ptr(), self.rec[f0:].data_ptr(), None)
+            asm.ctx.condensed_halo_pack(di, self.rec.data_ptr(), self.g.data_ptr(), self.halo_out.data_ptr())
+        self._exchange_start()
+        asm.ctx.condensed_ops(di, self.quad, self.stab, 0, n - top, self.rhs.data_ptr(), self.rec.data_ptr(), None)
+        self._tick(i, "ops")
+        self._exchange_wait()
+        self._tick(i, "exchange_wait")
+        asm.ctx.condensed_csr_fill(di, self.rec.data_ptr(), self.g.data_ptr(), None if self.halo_in is None else self.halo_in.data_ptr(),
+                                   self.values.data_ptr(), self.b.data_ptr())
+        self._tick(i, "fill")
+
+    def _exchange_start(self):
+        ci = self.ci
+        if self.comm is not None:
+            self.comm.halo_exchange_start(self.halo_out.data_ptr() if ci.halo_cells else None, int(ci.halo_cells) * ci.halo_doubles,
+                                          None if self.halo_in is None else self.halo_in.data_ptr(),
+                                          0 if self.halo_in is None else self.halo_in.numel())
+        elif self.host_exchange is not None:
+            self.host_exchange(self.halo_out if ci.halo_cells else None, self.halo_in)
+
+    def _exchange_wait(self):
+        if self.comm is not None:
+            self.comm.wait()
+
+    def stage_ms(self, steps):
+        """mean HIP-event time between the ticks of a step, per stage name"""
+        acc = {}
+        for i in range(steps):
+            ticks = self.ev[i]
+            for (a, ea), (b, eb) in zip(ticks[:-1], ticks[1:]):
+                acc[b] = acc.get(b, 0.0) + ea.elapsed_time(eb)
+        return {k: v / steps for k, v in acc.items()}
+
+    def check(self):
+        """the timed work produced finite, non-trivial results (not a cached / skipped pass)"""
+        torch = self.torch
+        if os.environ.get("PA_ABLATE"):      # (profiling-only stage ablation produces garbage on purpose)
+            return
+        probe = (self.lc if self.mode == "L" else self.rec)[:: max(1, self.n // 64)]
+        assert bool(torch.isfinite(probe).all()) and float(probe.abs().max()) > 0.0
+        if self.mode == "C":
+            v = self.values[:: max(1, self.values.numel() // 4096)]
+            assert bool(torch.isfinite(v).all()) and float(v.abs().max()) > 0.0 and bool(torch.isfinite(self.b).all())
+
+
+def timed(torch, dist, world, fn, steps, warmup, with_index=True):
+    for _ in range(warmup):
+        fn(None)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    oracle_lib.local_ops_batch(points, ptids, di, quad, stab, first=0, n=probe, fn=w["fn"], rhs_di=w["dinc"],
-                               want=("lc",))                       # warm-up + rate probe
-    rate = probe / (time.perf_counter() - t0)
-    if sample_rows <= 0:
-        sample_rows = max(1, min(N, int(target_seconds * rate / N)))
-    n = sample_rows * N
-    t0 = time.perf_counter()
-    st, _ = oracle_lib.local_ops_batch(points, ptids, di, quad, stab, first=0, n=n, fn=w["fn"], rhs_di=w["dinc"],
-                                       want=("lc",))
-    dt = time.perf_counter() - t0
-    assert st == 0
-    return {"value": n / dt, "unit": "cells/s", "cores": 1, "kind": "port",
-            "sample": "first %d of %d cell rows (%d cells) of the same mesh, %.1f s, oracle/hho_oracle.c "
-                      "(-O3 -mavx, single thread like the reference)" % (sample_rows, N, n, dt)}
+    for i in range(steps):
+        fn(i if with_index else None)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -154,24 +334,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="quad1024_k2", choices=sorted(WORKLOADS))
-    ap.add_argument("--exchange", default="allgather", choices=["allgather", "none"],
-                    help="N>1 only: all_gather of the condensed face-dof blocks at the end of every step")
-    ap.add_argument("--chunks", type=int, default=4,
-                    help="N>1 only: the local rows are processed in this many pieces; the all_gather of a piece overlaps the kernels of the next")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: quad1024_k2 on one GPU, quad2048_k3 (BASELINE.json's config 5) on several")
+    ap.add_argument("--mode", default=None, choices=["L", "C"],
+                    help="L: local operators + rhs to HBM (default on one GPU); C: condensed records + face-only CSR rows "
+                         "(default on several GPUs: the mode with the exchange)")
     ap.add_argument("--backend", default=os.environ.get("PA_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl = RCCL, one rank per GPU (what the driver runs); gloo = rehearsal of the N>1 code path with "
                          "several ranks sharing the visible GPU(s) and a host-staged exchange (numbers not comparable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="cell rows timed by the CPU baseline (0 = auto, ~15 s)")
+    ap.add_argument("--no-one-gpu-reference", action="store_true", help="N>1: skip the same step on rank 0's GPU alone")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="cell rows timed by the CPU baseline (0 = auto)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this pool
     import torch
     import torch.distributed as dist
     import proton_amd as pa
-    from proton_amd.batch import BatchAssembler
-    from proton_amd.partition import ChunkedExchange, condensed_per_cell, row_partition
+    from proton_amd.partition import row_partition
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -183,200 +363,132 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    workload = args.workload or ("quad1024_k2" if world == 1 else "quad2048_k3")
+    mode = args.mode or ("L" if world == 1 else "C")
+    w = WORKLOADS[workload]
+    N = w["N"]
+    if (w.get("cut") or w.get("perturb")) and (world > 1 or mode == "C"):
+        raise SystemExit("the cut and the general-quadrilateral workloads are single-GPU, mode L, in this round")
     rehearsal = world > 1 and args.backend == "gloo"
     if rehearsal:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    comm = None
+    host_exchange = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # torch.distributed carries the bootstrap (RCCL unique id), the barriers and the max over ranks of the timings;
+        # the exchange of the step itself goes through the library's own RCCL entry points (pa_comm_*)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+
+    r0, r1 = row_partition(N, world, rank)
+    pipe = Pipeline(torch, pa, w, mode, (r0, r1), N, local_rank)
+    if world > 1 and mode == "C":
         if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            from proton_amd.partition import HostStagedHalo
+            host_exchange = HostStagedHalo(rank, world)
+            pipe.host_exchange = host_exchange
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            ids = [pa.capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = pa.capi.Comm(pipe.asm.ctx, world, rank, ids[0])
+            pipe.comm = comm
         dist.barrier()                                     # communicators exist before anything is timed
 
-    w = WORKLOADS[args.workload]
-    N = w["N"]
-    quad = pa.QUAD_TENSOR if w["quad"] == "tensor" else pa.QUAD_FAN
-    stab = pa.STAB_FANCY if w["stab"] == "fancy" else pa.STAB_NAIVE
-    di, _ = pa.degree_info(w["cd"], w["fd"])
-    sz = pa.sizes_for(di, quad)
-    asm = BatchAssembler(local_rank)
-    r0, r1 = row_partition(N, world, rank)
-    cut = bool(w.get("cut"))
-    if cut:
-        if world > 1:
-            raise SystemExit("the cut workload is single-GPU in this round")
-        asm.cut_preprocess(N, refsteps=4)                    # host preprocessing: outside the timed region
-        # (side-stream overlap of the cut cells' kernel, pa_context_set_cut_overlap: measured SLOWER here, 0.75 vs 0.69 ms
-        # per step -- the persistent grid of the uncut cells' kernel holds the whole chip, the two only contend)
-        asm.ctx.set_cut_overlap(bool(os.environ.get("PA_CUT_OVERLAP")))
-    elif w.get("perturb"):
-        if world > 1:
-            raise SystemExit("the general-quadrilateral workload is single-GPU in this round")
-        mesh_keep = general_quad_mesh(torch, N, w["lo"], w["hi"], w["perturb"], asm.device)     # caller-owned device arrays
-        asm.ctx.mesh_attach_device(mesh_keep[0].data_ptr(), (N + 1) * (N + 1), mesh_keep[1].data_ptr(), N * N)
-    else:
-        asm.generate_mesh(N, N, w["lo"], w["hi"], rows=(r0, r1))
-    n_local = asm.ncells
-    dev = asm.device
+    elapsed = timed(torch, dist, world, pipe.step, args.steps, args.warmup)
+    stages = pipe.stage_ms(args.steps)
+    kern_ms = stages["ops"]
+    pipe.check()
 
-    lc = torch.empty((n_local, sz.msize, sz.msize), dtype=torch.float64, device=dev)
-    rhs = torch.empty((n_local, sz.cbs), dtype=torch.float64, device=dev)
-    out = {"lc": lc}
-    exchange = world > 1 and args.exchange == "allgather"
-    if exchange:
-        nf = 4 * sz.fbs
-        ex = ChunkedExchange(N, world, rank, condensed_per_cell(sz.fbs, packed=True), dev, args.chunks, host_staged=rehearsal)
-
-    if cut:
-        cut_lc = torch.empty((max(asm.ncut, 1), sz.msize, sz.msize), dtype=torch.float64, device=dev)
-        cut_rhs = torch.empty((max(asm.ncut, 1), sz.cbs), dtype=torch.float64, device=dev)
-
-    nchunks = ex.chunks if exchange else 1
-    k_start = [[torch.cuda.Event(enable_timing=True) for _ in range(nchunks)] for _ in range(args.steps)]
-    k_stop = [[torch.cuda.Event(enable_timing=True) for _ in range(nchunks)] for _ in range(args.steps)]
-
-    def step(i=None):
-        if not exchange:
-            if cut and asm.ncut:
-                # the cut cells first (on the context's side stream if PA_CUT_OVERLAP is set)
-                asm.ctx.cut_local_ops(w["fd"], asm.level_set, pa.capi.LOC_NEGATIVE, w["fn"], 2, None, None, None,
-                                      cut_lc.data_ptr(), cut_rhs.data_ptr(), None)
-            if i is not None:
-                k_start[i][0].record()
-            asm.local_ops(w["cd"], w["fd"], quad, stab, want=(), out=out)
-            if i is not None:
-                k_stop[i][0].record()
-            asm.cell_rhs(w["cd"], w["fn"], quad, dinc=w["dinc"], out=rhs)
-            if cut and asm.ncut:
-                asm.ctx.cut_merge(w["fd"], pa.capi.LOC_NEGATIVE, cut_lc.data_ptr(), cut_rhs.data_ptr(), lc.data_ptr(), rhs.data_ptr())
-            return
-        # N > 1: piece by piece; the collective of piece k overlaps the kernels of piece k + 1
-        for k in range(ex.chunks):
-            first, n = ex.piece_cells(k)
-            if i is not None:
-                k_start[i][k].record()
-            asm.ctx.local_ops(di, quad, stab, first, n, None, None, None, lc[first:first + n].data_ptr(), None)
-            if i is not None:
-                k_stop[i][k].record()
-            asm.ctx.cell_rhs(w["cd"], w["dinc"], quad, w["fn"], first, n, rhs[first:first + n].data_ptr(), None)
-            S_view, g_view = ex.local_S_g(k, nf)
-            asm.ctx.static_condensation_packed(di, n, lc[first:first + n].data_ptr(), rhs[first:first + n].data_ptr(),
-                                               S_view.data_ptr(), g_view.data_ptr(), None)
-            ex.exchange_async(k)
-        ex.wait()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
+    # N > 1: the same step, same mode, same code, whole mesh, on rank 0's GPU alone (the other ranks wait): the
+    # like-for-like one-GPU number of this run
+    one_gpu = None
+    if world > 1 and not args.no_one_gpu_reference:
+        if rank == 0:
+            ref = Pipeline(torch, pa, w, mode, (0, N), N, local_rank)
+            t_ref = timed(torch, dist, 1, ref.step, max(3, args.steps // 4), 1)
+            one_gpu = {"value": N * N / (t_ref / max(3, args.steps // 4)), "ms_per_step": t_ref / max(3, args.steps // 4) * 1e3}
+            del ref
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
 
-    kern_ms = sum(a.elapsed_time(b) for sa, sb in zip(k_start, k_stop) for a, b in zip(sa, sb)) / args.steps
-
-    # N > 1, informational (not `value`): the same K steps without the exchange -- local operators, right-hand
-    # sides and condensation of every rank's cells, no collective -- so that the cost of the all_gather is visible
-    elapsed_noex = None
-    if exchange:
-        def step_noex():
-            asm.ctx.local_ops(di, quad, stab, 0, n_local, None, None, None, lc.data_ptr(), None)
-            asm.ctx.cell_rhs(w["cd"], w["dinc"], quad, w["fn"], 0, n_local, rhs.data_ptr(), None)
-            for k in range(ex.chunks):
-                first, n = ex.piece_cells(k)
-                S_view, g_view = ex.local_S_g(k, nf)
-                asm.ctx.static_condensation_packed(di, n, lc[first:first + n].data_ptr(), rhs[first:first + n].data_ptr(),
-                                                   S_view.data_ptr(), g_view.data_ptr(), None)
-        step_noex()
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step_noex()
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-        elapsed_noex = time.perf_counter() - t1
-    t = torch.tensor([elapsed, kern_ms, elapsed_noex or 0.0], dtype=torch.float64, device="cpu" if rehearsal else dev)
+    t = torch.tensor([elapsed, kern_ms] + [stages.get(k, 0.0) for k in ("rhs", "exchange_wait", "fill")], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms, elapsed_noex = float(t[0]), float(t[1]), float(t[2])
-
-    # sanity: the timed work produced finite local matrices (not a cached / skipped result)
-    probe = lc[:: max(1, n_local // 64)]
-    if not os.environ.get("PA_ABLATE"):      # (profiling-only stage ablation produces garbage on purpose)
-        assert bool(torch.isfinite(probe).all()) and float(probe.abs().max()) > 0.0
-
-    if exchange:                             # every rank's condensed blocks arrived (finite, non-trivial)
-        for r in range(world):
-            Sg, gg = ex.gathered_S_g(r, 4 * sz.fbs)
-            pr = Sg[:: max(1, Sg.shape[0] // 16)]
-            assert bool(torch.isfinite(pr).all()) and float(pr.abs().max()) > 0.0, "gathered block of rank %d" % r
+    elapsed, kern_ms = float(t[0]), float(t[1])
+    stage_max = {"rhs": float(t[2]), "ops": kern_ms, "exchange_wait": float(t[3]), "fill": float(t[4])}
 
     if rank == 0:
+        sz, di, n_local = pipe.sz, pipe.di, pipe.n
         total_cells = N * N
         ms_per_step = elapsed / args.steps * 1e3
         value = total_cells / (elapsed / args.steps)
-        bpc = bytes_per_cell(sz.msize, sz.cbs)
-        li = asm.ctx.launch_info(di, quad, stab, n_local)
+        bpc = bytes_per_cell(mode, sz.msize, sz.cbs, sz.fbs)
+        li = pipe.asm.ctx.launch_info(di, pipe.quad, pipe.stab, n_local, condensed=(mode == "C"))
         achieved = n_local * bpc / (kern_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
-                rec = json.load(open(tf)).get(args.workload)
-                if rec and rec.get("n_gpus", 1) == world:
+                rec = json.load(open(tf)).get("%s|%s" % (workload, mode))
+                # counters are collected in separate rocprofv3 --pmc passes (tools/pmc.sh), not in this run: an entry is
+                # used only while the kernel time it was taken at still matches
+                if rec and rec.get("n_gpus", 1) == world and abs(rec.get("kernel_ms", 0.0) - kern_ms) <= 0.1 * kern_ms:
                     traffic = rec["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
+        fl = reference_flops_per_cell(w)
+        exch = "none"
+        if world > 1 and mode == "C":
+            exch = ("packed top-face rows of each slab's top cell row, one slab up (%d cells x %d doubles = %.2f MB per rank and step), %s"
+                    % (N, pipe.ci.halo_doubles, N * pipe.ci.halo_doubles * 8 / 1e6,
+                       "host-staged gloo (REHEARSAL, not RCCL)" if rehearsal else "RCCL send/recv through pa_comm_halo_exchange_start"))
         res = {
             "metric": BASELINE_METRIC,
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "mesh": "%dx%d quad_mesh on [%g,%g]^2 (reference generator)" % (N, N, w["lo"][0], w["hi"][0]),
+            "config": {"workload": workload, "mode": mode,
+                       "mesh": "%dx%d quad_mesh on [%g,%g]^2 (reference generator)" % (N, N, w["lo"][0], w["hi"][0]),
                        "hho_degree_info": [w["cd"], w["fd"]], "k": w["fd"], "quadrature": w["quad"], "stabilization": w["stab"],
-                       "cells": total_cells, "msize": sz.msize, "outputs": "lc (msize^2 f64) + cell rhs per cell, to HBM",
+                       "cells": total_cells, "msize": sz.msize,
+                       "outputs": ("lc (msize^2 f64) + cell rhs per cell, to HBM" if mode == "L" else
+                                   "cell rhs, packed condensed records (%d f64 per cell: upper triangle of the Schur complement + condensed rhs), "
+                                   "CSR values + right-hand side of the face-only system's owned rows" % pipe.ci.cond_doubles),
                        "parallelism": "cell rows block-partitioned over %d GPU(s)" % world,
-                       "exchange": (("static condensation + %s all_gather of the condensed face blocks (upper triangles, values only)"
-                                     % ("host-staged gloo (REHEARSAL, not RCCL)" if rehearsal else "RCCL")) if exchange else "none"),
-                       "note": w["note"]},
+                       "exchange": exch, "note": w["note"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": li.kernel_name.decode() + " + hho_cell_pre (its one-thread-per-cell pre-pass)",
                          "kernel_ms": kern_ms,
-                         "kernel_ms_is": "HIP events around the local-operator launches of one step (pre-pass + cooperative kernel where the path is split: the sum of their rocprofv3 averages)",
+                         "kernel_ms_is": "HIP events on the launch stream around the dominant kernel's launches of one step (pre-pass + cooperative "
+                                         "kernel: the sum of their rocprofv3 averages), mean over the timed steps, max over ranks",
                          "algorithmic_bytes_per_cell": bpc, "cells_per_launch": n_local,
                          "lanes_per_cell": li.lanes_per_cell, "grid_blocks": li.grid_blocks,
                          "lds_bytes_per_block": li.lds_bytes_per_block},
-            # the survey's second roof: the path is FP64-bound, not HBM-bound, for k >= 2 (arithmetic intensity of the
-            # reference's algorithm 17-25 flop/B against a machine balance of 9.8).  Informational: the kernel executes
-            # fewer flops than the reference's algorithm (cell integrals through moments), so this is work done per
-            # reference flop, not an instruction-level utilisation.
-            "roofline_fp64": (lambda fl: None if fl is None else {
+            # the survey's second roof: the path is FP64-bound, not HBM-bound, for k >= 2.  Informational: the kernel executes
+            # fewer flops than the reference's algorithm (cell integrals through moments, data + stab through one Z^T Z), so
+            # this is reference work done per second, not an instruction-level utilisation.
+            "roofline_fp64": None if fl is None else {
                 "bound": "fp64", "achieved": n_local * fl / (kern_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": n_local * fl / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                "reference_flops_per_cell": fl, "source": "SURVEY.md 8(d) operation-count model of the reference's algorithm, +-30 %"})(
-                    REFERENCE_FLOPS_PER_CELL.get((w["cd"], w["fd"], w["quad"], w["stab"]))),
-            "without_exchange": None if not exchange else {
-                "value": total_cells / (elapsed_noex / args.steps), "unit": "cells/s", "ms_per_step": elapsed_noex / args.steps * 1e3,
-                "what": "the same steps (local operators + rhs + condensation on every rank) without the all_gather, max over ranks"},
-            "kernel_only_cells_per_s": total_cells / (kern_ms * 1e-3) if world == 1 else n_local * world / (kern_ms * 1e-3),
+                "reference_flops_per_cell": fl,
+                "source": "exact count of the instrumented CPU restatement (oracle/flopcount -> oracle/flops_per_cell.json)"},
+            "stage_ms": stage_max,
+            "kernel_only_cells_per_s": n_local * world / (kern_ms * 1e-3),
+            "same_step_one_gpu": None if one_gpu is None else dict(one_gpu, unit="cells/s", speedup=value / one_gpu["value"],
+                                                                   what="the identical step (mode %s, whole mesh) on rank 0's GPU alone" % mode),
         }
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline_cut(w) if cut else cpu_baseline(w, args.cpu_sample_rows)
+            res["cpu_baseline"] = cpu_baseline_cut(w) if pipe.cut else cpu_baseline(w, args.cpu_sample_rows)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
 
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 1
+#define PA_ABI_VERSION 2
 
 /* status codes (reference: C++ exceptions / silent NaNs) */
 enum {
@@ -37,7 +37,8 @@ enum {
                                       rules[8] hole of the fan quadrature (quadratures_dunavant.hpp:129) */
     PA_ERR_HIP = 4,                /* a HIP runtime call failed; see pa_last_error()               */
     PA_ERR_NO_MESH = 5,
-    PA_ERR_NOT_SPD = 6             /* some cell had a non-positive Cholesky pivot (Eigen LLT: silent) */
+    PA_ERR_NOT_SPD = 6,            /* some cell had a non-positive Cholesky pivot (Eigen LLT: silent) */
+    PA_ERR_COMM = 7                /* RCCL missing or an RCCL call failed; see pa_comm_last_error()  */
 };
 
 /* integrate() overloads: quadratures.hpp:311-375 (quad_mesh, tensor Gauss) and
@@ -197,6 +198,11 @@ typedef struct {
                                     slab below: pa_condensed_csr_fill expects d_halo_below            */
 } pa_condensed_info;
 int pa_condensed_query(pa_context *ctx, pa_degree_info di, pa_condensed_info *out);
+/* The row partition alone, in closed form, for the slab [row_begin, row_end) of the Nx x Ny generator mesh: what
+ * pa_condensed_query reports for such a context, without a context or a device (nnz_owned is left 0).  Lets a driver
+ * size its buffers and its exchange before any rank has touched its GPU. */
+int pa_condensed_partition_info(size_t Nx, size_t Ny, size_t row_begin, size_t row_end, pa_degree_info di,
+                                pa_condensed_info *out);
 
 /* assembler::assemble (hho.hpp:344-406) on the condensed blocks, cells [first, first+n): per cell nf^2
  * triplet slots in the reference's push order restricted to the face unknowns (slot i*nf + j for face
@@ -438,6 +444,35 @@ int pa_interface_triplets_batch(pa_context *ctx, int face_deg, const double *d_l
  * offset in the solution of the cell block of the negative / positive side (equal for uncut cells) */
 int pa_interface_cell_offsets(pa_context *ctx, int face_deg, int64_t *d_offsets);
 
+/* ---- multi-GPU exchange: one process per GPU, RCCL over xGMI ------------
+ * The reference is a single process without any communication.  Cells shard by rows (pa_mesh_generate's
+ * row_begin / row_end); every rank assembles the CSR rows of the faces it owns (pa_condensed_csr_fill), and the only
+ * data a step moves between ranks are the packed top-face rows of a slab's top cell row (pa_condensed_halo_pack),
+ * one slab up: rank r -> rank r + 1, halo_cells x halo_doubles doubles.  RCCL is bound at run time (dlopen; a copy
+ * the process already holds, e.g. PyTorch's, is used), so the library loads without it.
+ * Bootstrap as with NCCL: rank 0 calls pa_comm_unique_id and hands the PA_COMM_ID_BYTES to the other ranks (MPI,
+ * a file, torch.distributed's store ...); every rank then calls pa_comm_create with its context.
+ * The *_start calls are ordered after everything already enqueued on the context's stream and run on a stream of the
+ * communicator, next to whatever the context enqueues afterwards; pa_comm_wait orders the context's stream behind
+ * them.  Ranks in slab order: rank r owns the cell rows below those of rank r + 1. */
+#define PA_COMM_ID_BYTES 128
+typedef struct pa_comm pa_comm;
+int pa_comm_unique_id(void *id_out, size_t bytes);
+int pa_comm_create(pa_context *ctx, int nranks, int rank, const void *unique_id, pa_comm **out);
+int pa_comm_destroy(pa_comm *comm);
+int pa_comm_info(pa_comm *comm, int *nranks, int *rank);
+const char *pa_comm_last_error(pa_comm *comm);
+/* d_send_up: this rank's pa_condensed_halo_pack output (ignored on the last rank); d_recv_below: where the rows of
+ * the rank below land (ignored on rank 0); counts in doubles */
+int pa_comm_halo_exchange_start(pa_comm *comm, const double *d_send_up, size_t send_count,
+                                double *d_recv_below, size_t recv_count);
+/* every rank's bytes_per_rank bytes to every rank, in rank order (the north star's all-gather of the face-dof
+ * blocks, for a caller that wants the whole system on one device) */
+int pa_comm_allgather_start(pa_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);
+/* in-place sum over the ranks (the dot products of a distributed solve) */
+int pa_comm_allreduce_sum_start(pa_comm *comm, double *d_buf, size_t count);
+int pa_comm_wait(pa_comm *comm);
+
 /* occupancy / launch facts of the dominant kernel for the roofline bookkeeping */
 typedef struct {
     int32_t lanes_per_cell, cells_per_block, block_threads, lds_bytes_per_block;
@@ -445,6 +480,9 @@ typedef struct {
     const char *kernel_name;
 } pa_launch_info;
 int pa_local_ops_launch_info(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind,
+                             size_t n, pa_launch_info *out);
+/* the same for the condensed-mode instance (pa_condensed_ops_batch) */
+int pa_condensed_launch_info(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind,
                              size_t n, pa_launch_info *out);
 
 #ifdef __cplusplus

@@ -11,6 +11,10 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define IDX(i, j, ld) ((size_t)(i) + (size_t)(j) * (size_t)(ld))
 
@@ -1063,3 +1067,186 @@ int hho_local_ops_batch(const double *points, const uint64_t *cell_ptids, size_t
     }
     return worst;
 }
+
+/* ------------------------------------------------------------------ */
+/* CPU baseline of bench.py        */
+/* ------------------------------------------------------------------ */
+#ifndef HHO_FLOPCOUNT      /* (not part of the counted restatement: oracle/flopcount.cpp) */
+static double wall_seconds(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int hho_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* The per-cell loop of the reference's drivers over cells [first, first + n), `nthreads` threads over cells
+ * (1 = the reference: it is single-threaded).  Same arithmetic per cell as hho_local_ops_batch. */
+int hho_local_ops_batch_mt(const double *points, const uint64_t *cell_ptids, size_t first, size_t n,
+                           hho_degrees di, int quad_kind, int stab_kind, hho_scalar_fn f, void *user, int rhs_di,
+                           double *out_lc, double *out_rhs, int nthreads)
+{
+    int cbs = hho_cell_basis_size(di.cell_deg), fbs = hho_face_basis_size(di.face_deg), msize = cbs + 4 * fbs;
+    size_t mm = (size_t)msize * msize;
+    int worst = HHO_OK;
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static) reduction(max : worst)
+#endif
+    for (long long c = 0; c < (long long)n; c++) {
+        int st = hho_local_ops_batch(points, cell_ptids, first + (size_t)c, 1, di, quad_kind, stab_kind, f, user, rhs_di,
+                                     NULL, NULL, NULL, out_lc ? out_lc + (size_t)c * mm : NULL,
+                                     out_rhs ? out_rhs + (size_t)c * cbs : NULL);
+        if (st > worst) worst = st;
+    }
+    return worst;
+}
+
+typedef struct { int32_t col; double val; } csr_ent;
+static int csr_ent_cmp(const void *a, const void *b)
+{
+    int32_t x = ((const csr_ent *)a)->col, y = ((const csr_ent *)b)->col;
+    return x < y ? -1 : x > y;
+}
+
+/* SparseMatrix::setFromTriplets (hho.hpp:451-455): rows bucketed by a counting pass in push order, every row sorted
+ * by column (stable for equal columns: qsort on a key that includes the push position) and duplicates summed.
+ * Returns nnz; rowptr nrows + 1, colind / values with room for ntrip entries. */
+size_t hho_set_from_triplets(size_t ntrip, const int32_t *rows, const int32_t *cols, const double *vals, size_t nrows,
+                             int64_t *rowptr, int32_t *colind, double *values, int nthreads)
+{
+    int64_t *count = (int64_t *)calloc(nrows + 1, sizeof(int64_t));
+    for (size_t t = 0; t < ntrip; t++) if (rows[t] >= 0) count[rows[t] + 1]++;
+    for (size_t r = 0; r < nrows; r++) count[r + 1] += count[r];
+    size_t total = (size_t)count[nrows];
+    csr_ent *ent = (csr_ent *)malloc(sizeof(csr_ent) * (total ? total : 1));
+    int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * (nrows + 1));
+    memcpy(fill, count, sizeof(int64_t) * (nrows + 1));
+    for (size_t t = 0; t < ntrip; t++) {
+        if (rows[t] < 0) continue;
+        int64_t pos = fill[rows[t]]++;
+        ent[pos].col = cols[t]; ent[pos].val = vals[t];
+    }
+    int64_t *rowlen = (int64_t *)malloc(sizeof(int64_t) * (nrows + 1));
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for (long long r = 0; r < (long long)nrows; r++) {
+        csr_ent *e = ent + count[r];
+        int64_t m = count[r + 1] - count[r], k = 0;
+        /* insertion sort: stable, rows are short (<= 4 msize entries) and arrive almost sorted */
+        for (int64_t i = 1; i < m; i++) {
+            csr_ent x = e[i]; int64_t j = i - 1;
+            while (j >= 0 && e[j].col > x.col) { e[j + 1] = e[j]; j--; }
+            e[j + 1] = x;
+        }
+        for (int64_t i = 0; i < m; i++) {
+            if (k > 0 && e[k - 1].col == e[i].col) e[k - 1].val += e[i].val;
+            else e[k++] = e[i];
+        }
+        rowlen[r] = k;
+    }
+    (void)csr_ent_cmp;
+    size_t nnz = 0;
+    for (size_t r = 0; r < nrows; r++) {
+        rowptr[r] = (int64_t)nnz;
+        const csr_ent *e = ent + count[r];
+        for (int64_t i = 0; i < rowlen[r]; i++) { colind[nnz] = e[i].col; values[nnz] = e[i].val; nnz++; }
+    }
+    rowptr[nrows] = (int64_t)nnz;
+    free(count); free(ent); free(fill); free(rowlen);
+    return nnz;
+}
+
+/* The span the reference labels "Matrix assembly" (apps/cuthho/cuthho_square.cpp:881-905, apps/obstacle/obstacle.cpp:145-161,
+ * apps/convergence_test/convergence_test.cpp:201-217) on the generator mesh, cell rows [row_begin, row_end) of it:
+ * make_assembler, then per cell make_hho_laplacian + stabilization + make_rhs + assembler.assemble, then finalize.
+ * seconds[0]: the per-cell operators + rhs alone; seconds[1]: the whole span (operators recomputed).  The system has
+ * the full mesh's numbering; only the sampled rows contribute.  checksum: sum of the CSR values (keeps the work live). */
+int hho_matrix_assembly_timed(const hho_mesh_params *mp, size_t row_begin, size_t row_end, hho_degrees di, int quad_kind,
+                              int stab_kind, int rhs_fn, int bcs_fn, int rhs_di, int nthreads, double seconds[2],
+                              size_t *nnz_out, double *checksum)
+{
+    size_t np = hho_mesh_num_points(mp), nc = hho_mesh_num_cells(mp), nf = hho_mesh_num_faces(mp);
+    if (row_end > mp->Ny || row_begin >= row_end) return HHO_ERR_DEGREE;
+    int cbs = hho_cell_basis_size(di.cell_deg), fbs = hho_face_basis_size(di.face_deg), msize = cbs + 4 * fbs;
+    size_t mm = (size_t)msize * msize, n = (row_end - row_begin) * mp->Nx, first = row_begin * mp->Nx;
+    double *points = (double *)malloc(sizeof(double) * 2 * np);
+    uint64_t *ptids = (uint64_t *)malloc(sizeof(uint64_t) * 4 * nc);
+    hho_mesh_generate(mp, points, ptids);
+    hho_scalar_fn f = hho_builtin_fn(rhs_fn), bf = hho_builtin_fn(bcs_fn);
+    if (nthreads < 1) nthreads = 1;
+    int status = HHO_OK;
+
+    /* (a) operators + rhs only */
+    double *lc = (double *)malloc(sizeof(double) * mm * n), *rhs = (double *)malloc(sizeof(double) * (size_t)cbs * n);
+    double t0 = wall_seconds();
+    status = hho_local_ops_batch_mt(points, ptids, first, n, di, quad_kind, stab_kind, f, NULL, rhs_di, lc, rhs, nthreads);
+    seconds[0] = wall_seconds() - t0;
+    if (status && status != HHO_ERR_NOT_SPD) { free(points); free(ptids); free(lc); free(rhs); return status; }
+
+    /* (b) the whole span */
+    t0 = wall_seconds();
+    /* make_assembler: face list and compress table (hho.hpp:298-335) */
+    uint64_t *faces = (uint64_t *)malloc(sizeof(uint64_t) * 2 * nf);
+    uint8_t *is_bnd = (uint8_t *)malloc(nf);
+    int64_t *compress = (int64_t *)malloc(sizeof(int64_t) * nf);
+    hho_mesh_generate_faces(mp, faces, is_bnd);
+    size_t num_other = hho_assembler_compress_table(is_bnd, nf, compress);
+    size_t system_size = hho_assembler_system_size(di, nc, num_other);
+    int32_t *tr = (int32_t *)malloc(sizeof(int32_t) * mm * n), *tc = (int32_t *)malloc(sizeof(int32_t) * mm * n);
+    double *tv = (double *)malloc(sizeof(double) * mm * n);
+    int64_t *rrows = (int64_t *)malloc(sizeof(int64_t) * (size_t)msize * n);
+    double *rvals = (double *)malloc(sizeof(double) * (size_t)msize * n);
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for (long long cc = 0; cc < (long long)n; cc++) {
+        size_t c = first + (size_t)cc, ci = c % mp->Nx, cj = c / mp->Nx;
+        double lcl[HHO_MAX_MSIZE * HHO_MAX_MSIZE], rl[HHO_MAX_RBS], dd[HHO_MAX_MSIZE];
+        hho_local_ops_batch(points, ptids, c, 1, di, quad_kind, stab_kind, f, NULL, rhs_di, NULL, NULL, NULL, lcl, rl);
+        uint64_t fids[4]; uint8_t fdir[4];
+        memset(dd, 0, sizeof(dd));
+        for (int lf = 0; lf < 4; lf++) {
+            fids[lf] = hho_mesh_face_id(mp, ci, cj, lf);
+            fdir[lf] = is_bnd[fids[lf]];
+            if (fdir[lf]) {                                       /* hho.hpp:381-386 */
+                const double *p0 = points + 2 * faces[2 * fids[lf]], *p1 = points + 2 * faces[2 * fids[lf] + 1];
+                hho_dirichlet_face_data(p0, p1, di.face_deg, bf, NULL, dd + cbs + lf * fbs);
+            }
+        }
+        /* assemble() pushes only the assembled pairs: the unused tail of the cell's slots is marked -1 */
+        size_t nt = 0;
+        int32_t *r_ = tr + (size_t)cc * mm, *c_ = tc + (size_t)cc * mm;
+        hho_assembler_assemble_cell(di, c, nc, fids, fdir, compress, lcl, rl, dd, r_, c_, tv + (size_t)cc * mm, &nt,
+                                    rrows + (size_t)cc * msize, rvals + (size_t)cc * msize);
+        for (size_t t = nt; t < mm; t++) { r_[t] = -1; c_[t] = -1; }
+    }
+    double *RHS = (double *)calloc(system_size ? system_size : 1, sizeof(double));
+    for (size_t t = 0; t < (size_t)msize * n; t++) if (rrows[t] >= 0) RHS[rrows[t]] += rvals[t];
+    /* finalize (hho.hpp:451-455) */
+    int64_t *rowptr = (int64_t *)malloc(sizeof(int64_t) * (system_size + 1));
+    int32_t *colind = (int32_t *)malloc(sizeof(int32_t) * mm * n);
+    double *values = (double *)malloc(sizeof(double) * mm * n);
+    size_t nnz = hho_set_from_triplets(mm * n, tr, tc, tv, system_size, rowptr, colind, values, nthreads);
+    seconds[1] = wall_seconds() - t0;
+    double cs = 0.0;
+    for (size_t t = 0; t < nnz; t++) cs += values[t];
+    for (size_t t = 0; t < system_size; t++) cs += RHS[t];
+    for (size_t t = 0; t < mm * n; t++) cs += lc[t] * 0.0;
+    if (checksum) *checksum = cs;
+    if (nnz_out) *nnz_out = nnz;
+    free(points); free(ptids); free(lc); free(rhs); free(faces); free(is_bnd); free(compress); free(tr); free(tc); free(tv);
+    free(rrows); free(rvals); free(RHS); free(rowptr); free(colind); free(values);
+    return status;
+}
+#endif /* HHO_FLOPCOUNT */

@@ -104,7 +104,7 @@ def build(force=False, verbose=False, jobs=None):
              else PER_CONFIG_FLAGS.get((cd, fd, q), []))
         if force or _stale(obj, defs, newest):
             todo.append((os.path.join(CSRC, "hho_inst.hip"), obj, defs))
-    for unit in ("capi", "csr", "solver", "condensed"):
+    for unit in ("capi", "csr", "solver", "condensed", "comm"):
         unit_obj = os.path.join(OBJ_DIR, unit + ".o")
         objs.append(unit_obj)
         if force or _stale(unit_obj, [], newest):
@@ -118,7 +118,7 @@ def build(force=False, verbose=False, jobs=None):
                 if verbose:
                     print("  built", os.path.basename(obj), flush=True)
     if todo or not os.path.exists(LIB_PATH):
-        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stderr[-4000:]))

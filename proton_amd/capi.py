@@ -14,7 +14,7 @@ STAB_NONE, STAB_NAIVE, STAB_FANCY = 0, 1, 2
 FN_SAMPLED, FN_SIN_SIN_RHS, FN_SIN_SIN_SOL, FN_OBSTACLE_RHS, FN_OBSTACLE_SOL, FN_ONE = range(6)
 
 STATUS = {0: "PA_OK", 1: "PA_ERR_INVALID_ARG", 2: "PA_ERR_INVALID_DEGREE", 3: "PA_ERR_QUADRATURE",
-          4: "PA_ERR_HIP", 5: "PA_ERR_NO_MESH", 6: "PA_ERR_NOT_SPD"}
+          4: "PA_ERR_HIP", 5: "PA_ERR_NO_MESH", 6: "PA_ERR_NOT_SPD", 7: "PA_ERR_COMM"}
 
 # every symbol include/proton_amd.h declares
 EXPORTS = [
@@ -34,7 +34,9 @@ EXPORTS = [
     "pa_interface_triplets_batch", "pa_interface_cell_offsets",
     "pa_condensed_ops_batch", "pa_condensed_recover_batch", "pa_condensed_query", "pa_condensed_triplets_batch",
     "pa_condensed_csr_pattern", "pa_condensed_csr_fill", "pa_condensed_halo_pack", "pa_condensed_take_faces",
-    "pa_condensed_expand_solution",
+    "pa_condensed_expand_solution", "pa_condensed_launch_info", "pa_condensed_partition_info",
+    "pa_comm_unique_id", "pa_comm_create", "pa_comm_destroy", "pa_comm_info", "pa_comm_last_error",
+    "pa_comm_halo_exchange_start", "pa_comm_allgather_start", "pa_comm_allreduce_sum_start", "pa_comm_wait",
 ]
 
 
@@ -170,6 +172,18 @@ def lib():
     L.pa_condensed_halo_pack.argtypes = [vp, DegreeInfo, dp, dp, dp]
     L.pa_condensed_take_faces.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp]
     L.pa_condensed_expand_solution.argtypes = [vp, DegreeInfo, dp, dp, dp]
+    L.pa_condensed_launch_info.argtypes = [vp, DegreeInfo, C.c_int, C.c_int, sz, C.POINTER(LaunchInfo)]
+    L.pa_condensed_partition_info.argtypes = [sz, sz, sz, sz, DegreeInfo, C.POINTER(CondensedInfo)]
+    L.pa_comm_unique_id.argtypes = [vp, sz]
+    L.pa_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.pa_comm_destroy.argtypes = [vp]
+    L.pa_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pa_comm_last_error.argtypes = [vp]
+    L.pa_comm_last_error.restype = C.c_char_p
+    L.pa_comm_halo_exchange_start.argtypes = [vp, dp, sz, dp, sz]
+    L.pa_comm_allgather_start.argtypes = [vp, dp, dp, sz]
+    L.pa_comm_allreduce_sum_start.argtypes = [vp, dp, sz]
+    L.pa_comm_wait.argtypes = [vp]
     _lib = L
     return L
 
@@ -186,6 +200,67 @@ def sizes_for(di, quad):
     if st != 0:
         raise ProtonAmdError(st, "pa_sizes_for")
     return s
+
+
+def condensed_partition_info(Nx, Ny, rows, di):
+    """closed-form row partition of the face-only system for the slab `rows` (no context, no device)"""
+    out = CondensedInfo()
+    st = lib().pa_condensed_partition_info(Nx, Ny, rows[0], rows[1], di, C.byref(out))
+    if st != 0:
+        raise ProtonAmdError(st, "pa_condensed_partition_info")
+    return out
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """bytes of a fresh RCCL unique id (rank 0; hand it to the other ranks)"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    st = lib().pa_comm_unique_id(buf, COMM_ID_BYTES)
+    if st != 0:
+        raise ProtonAmdError(st, "pa_comm_unique_id", "is librccl loadable?")
+    return buf.raw
+
+
+class Comm:
+    """pa_comm: the RCCL communicator of one rank's context (one process per GPU)."""
+
+    def __init__(self, ctx, nranks, rank, unique_id):
+        self._L = lib()
+        h = C.c_void_p()
+        idb = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        st = self._L.pa_comm_create(ctx.h, nranks, rank, idb, C.byref(h))
+        if st != 0:
+            raise ProtonAmdError(st, "pa_comm_create")
+        self.h, self.nranks, self.rank = h, nranks, rank
+
+    def _ck(self, st, where):
+        if st != 0:
+            raise ProtonAmdError(st, where, self._L.pa_comm_last_error(self.h).decode())
+
+    def halo_exchange_start(self, send_up, send_count, recv_below, recv_count):
+        self._ck(self._L.pa_comm_halo_exchange_start(self.h, send_up, send_count, recv_below, recv_count), "pa_comm_halo_exchange_start")
+
+    def allgather_start(self, send, recv, bytes_per_rank):
+        self._ck(self._L.pa_comm_allgather_start(self.h, send, recv, bytes_per_rank), "pa_comm_allgather_start")
+
+    def allreduce_sum_start(self, buf, count):
+        self._ck(self._L.pa_comm_allreduce_sum_start(self.h, buf, count), "pa_comm_allreduce_sum_start")
+
+    def wait(self):
+        self._ck(self._L.pa_comm_wait(self.h), "pa_comm_wait")
+
+    def close(self):
+        if self.h:
+            self._L.pa_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -421,7 +496,10 @@ class Context:
     def condensed_expand_solution(self, di, uT, xF, full):
         self._ck(self._L.pa_condensed_expand_solution(self.h, di, uT, xF, full), "pa_condensed_expand_solution")
 
-    def launch_info(self, di, quad, stab, n):
+    def launch_info(self, di, quad, stab, n, condensed=False):
         li = LaunchInfo()
-        self._ck(self._L.pa_local_ops_launch_info(self.h, di, quad, stab, n, C.byref(li)), "pa_local_ops_launch_info")
+        if condensed:
+            self._ck(self._L.pa_condensed_launch_info(self.h, di, quad, stab, n, C.byref(li)), "pa_condensed_launch_info")
+        else:
+            self._ck(self._L.pa_local_ops_launch_info(self.h, di, quad, stab, n, C.byref(li)), "pa_local_ops_launch_info")
         return li

@@ -91,6 +91,7 @@ struct pa_context {
     // condensed (face-only) assembly: face adjacency and the symbolic records of the owned faces, built on first use
     int32_t *d_adj = nullptr;
     pa::CondFace *d_cfaces = nullptr;
+    pa::CondFaceLean *d_cfaces_lean = nullptr;
     uint32_t *d_ncols = nullptr, *d_prefix = nullptr;
     bool cond_ready = false;
     uint32_t cond_nown = 0, cond_owned_range = 0;
@@ -140,6 +141,8 @@ static void release_faces(pa_context *ctx)
     ctx->nfaces_local = ctx->face_base = ctx->num_other_faces = 0;
     if (ctx->d_adj) (void)hipFree(ctx->d_adj);
     if (ctx->d_cfaces) (void)hipFree(ctx->d_cfaces);
+    if (ctx->d_cfaces_lean) (void)hipFree(ctx->d_cfaces_lean);
+    ctx->d_cfaces_lean = nullptr;
     if (ctx->d_ncols) (void)hipFree(ctx->d_ncols);
     if (ctx->d_prefix) (void)hipFree(ctx->d_prefix);
     ctx->d_adj = nullptr; ctx->d_cfaces = nullptr; ctx->d_ncols = ctx->d_prefix = nullptr;
@@ -189,6 +192,10 @@ static hipError_t upload_vec(const std::vector<T> &v, T **d, hipStream_t s)
     if (e == hipSuccess && !v.empty()) e = hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
     return e;
 }
+
+// accessors for comm.hip (internal to the library)
+extern "C" __attribute__((visibility("hidden"))) void *pa_context_stream_(pa_context *ctx) { return (void *)ctx->stream; }
+extern "C" __attribute__((visibility("hidden"))) int pa_context_device_(pa_context *ctx) { return ctx->device; }
 
 extern "C" {
 
@@ -834,20 +841,30 @@ int pa_condensed_recover_batch(pa_context *ctx, pa_degree_info di, int quad_kind
     return run_local_ops(ctx, di, quad_kind, stab_kind, first, n, o);
 }
 
-int pa_local_ops_launch_info(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t n, pa_launch_info *out)
+static int launch_info(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t n, bool cond, pa_launch_info *out)
 {
     if (!ctx || !out) return PA_ERR_INVALID_ARG;
     const pa::KernelEntry *e = nullptr;
     int grid = 0;
-    const int st = select_kernel(ctx, di, quad_kind, stab_kind, n, &e, &grid);
+    const int st = select_kernel(ctx, di, quad_kind, stab_kind, n, &e, &grid, cond);
     if (st != PA_OK) return st;
     out->lanes_per_cell = e->lanes_per_cell;
     out->cells_per_block = 64 / e->lanes_per_cell;
     out->block_threads = 64;
-    out->lds_bytes_per_block = e->lds_bytes;
+    out->lds_bytes_per_block = cond ? e->lds_bytes_cond : e->lds_bytes;
     out->grid_blocks = grid;
-    out->kernel_name = e->name;
+    out->kernel_name = cond ? e->name_cond : e->name;
     return PA_OK;
+}
+
+int pa_local_ops_launch_info(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t n, pa_launch_info *out)
+{
+    return launch_info(ctx, di, quad_kind, stab_kind, n, false, out);
+}
+
+int pa_condensed_launch_info(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t n, pa_launch_info *out)
+{
+    return launch_info(ctx, di, quad_kind, stab_kind, n, true, out);
 }
 
 }  // extern "C"
@@ -1075,14 +1092,41 @@ static int cond_prepare(pa_context *ctx)
     }
     PA_HIP(ctx, hipMalloc((void **)&ctx->d_adj, (ctx->nfaces_local ? ctx->nfaces_local : 1) * 2 * sizeof(int32_t)));
     PA_HIP(ctx, hipMalloc((void **)&ctx->d_cfaces, ((size_t)nown + 1) * sizeof(pa::CondFace)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_cfaces_lean, ((size_t)nown + 1) * sizeof(pa::CondFaceLean)));
     PA_HIP(ctx, hipMalloc((void **)&ctx->d_ncols, ((size_t)nown + 1) * sizeof(uint32_t)));
     PA_HIP(ctx, hipMalloc((void **)&ctx->d_prefix, ((size_t)nown + 1) * sizeof(uint32_t)));
     PA_HIP(ctx, pa::cond_build_tables(ctx->stream, cond_mesh(ctx), (uint32_t)ctx->nfaces_local, (uint32_t)ctx->ncells, owned_range, p0,
-                                      nown, ctx->d_adj, ctx->d_cfaces, ctx->d_ncols, ctx->d_prefix));
+                                      nown, ctx->d_adj, ctx->d_cfaces, ctx->d_cfaces_lean, ctx->d_ncols, ctx->d_prefix));
     uint32_t total = 0;
     PA_HIP(ctx, hipMemcpy(&total, ctx->d_prefix + nown, sizeof(uint32_t), hipMemcpyDeviceToHost));
     ctx->cond_nown = nown; ctx->cond_owned_range = owned_range; ctx->cond_p0 = p0; ctx->cond_total_cols = total;
     ctx->cond_ready = true;
+    return PA_OK;
+}
+
+// the part of pa_condensed_info a slab's closed forms determine
+static void cond_partition_fill(const pa::StructuredMesh &sm, uint64_t fbs, pa_condensed_info *out)
+{
+    const int32_t p0 = sm_first_compress_from(sm, sm.row0 * pa::sm_face_row(sm));
+    const int32_t p1 = sm_first_compress_from(sm, sm.row1 * pa::sm_face_row(sm));
+    out->num_other_faces = pa::sm_num_other_faces(sm);
+    out->system_size = fbs * out->num_other_faces;
+    out->nf = (int32_t)(4 * fbs);
+    out->cond_doubles = (int32_t)(4 * fbs * (4 * fbs + 1) / 2 + 4 * fbs);
+    out->row_begin = (uint64_t)p0 * fbs;
+    out->row_end = (uint64_t)p1 * fbs;
+    out->nnz_owned = 0;
+    out->halo_cells = sm.row1 < sm.Ny ? sm.Nx : 0;
+    out->halo_doubles = (int32_t)(fbs * (4 * fbs + 1));
+    out->has_below = sm.row0 > 0 ? 1 : 0;
+}
+
+int pa_condensed_partition_info(size_t Nx, size_t Ny, size_t row_begin, size_t row_end, pa_degree_info di, pa_condensed_info *out)
+{
+    if (!out || !cond_degree_ok(di) || Nx == 0 || Ny == 0 || row_begin >= row_end || row_end > Ny) return PA_ERR_INVALID_ARG;
+    if ((Nx + 1) * (Ny + 1) >= ((size_t)1 << 32)) return PA_ERR_INVALID_ARG;
+    const pa::StructuredMesh sm = {(uint32_t)Nx, (uint32_t)Ny, (uint32_t)row_begin, (uint32_t)row_end};
+    cond_partition_fill(sm, (uint64_t)di.face_deg + 1, out);
     return PA_OK;
 }
 
@@ -1140,7 +1184,7 @@ int pa_condensed_csr_fill(pa_context *ctx, pa_degree_info di, const double *d_co
         return PA_ERR_INVALID_ARG;
     }
     PA_HIP(ctx, hipSetDevice(ctx->device));
-    PA_HIP(ctx, pa::cond_fill(ctx->stream, cond_mesh(ctx), ctx->cond_nown, di.face_deg + 1, ctx->d_cfaces, ctx->d_prefix, d_cond, d_g,
+    PA_HIP(ctx, pa::cond_fill(ctx->stream, cond_mesh(ctx), ctx->cond_nown, di.face_deg + 1, ctx->d_cfaces_lean, ctx->d_prefix, d_cond, d_g,
                               d_halo_below, d_values, d_rhs));
     return PA_OK;
 }

@@ -104,7 +104,7 @@ __device__ inline void cond_describe_face(const CondMesh &m, uint32_t f, int32_t
 
 // one thread per local face: owned non-Dirichlet faces write their record at position compress - p0
 __global__ __launch_bounds__(256) void cond_symbolic_kernel(CondMesh m, uint32_t nfaces_owned_range, int32_t p0, uint32_t nown,
-                                                            CondFace *faces, uint32_t *ncols)
+                                                            CondFace *faces, CondFaceLean *lean, uint32_t *ncols)
 {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nfaces_owned_range) return;
@@ -120,6 +120,11 @@ __global__ __launch_bounds__(256) void cond_symbolic_kernel(CondMesh m, uint32_t
     r.face = f;
     faces[q] = r;
     ncols[q] = (uint32_t)ncol;
+    CondFaceLean ln;
+    ln.cA = r.cA; ln.cB = r.cB;
+    ln.packed = ((uint64_t)r.rows << 42) | ((uint64_t)ncol << 46);
+    for (int s = 0; s < 7; ++s) ln.packed |= (uint64_t)(r.code[s] & 63) << (6 * s);
+    lean[q] = ln;
 }
 
 // rowptr / colind of the owned rows for one fbs: row (q, k) starts at fbs^2 prefix[q] + k fbs ncol[q]
@@ -157,45 +162,95 @@ __device__ __forceinline__ double cond_rhs_contrib(const CondMesh &m, const doub
 }
 
 // numeric phase: one thread per CSR entry of a face's rows -- (row k, column slot s, column k') with k' fastest, so
-// that consecutive threads write consecutive entries; 7 fbs^2 threads per owned face, the tail idle where a face has
-// fewer than 7 column faces.  The thread of (k, 0, 0) also forms the right-hand side of row (q, k).
-__global__ __launch_bounds__(256) void cond_fill_kernel(CondMesh m, uint32_t nown, int fbs, const CondFace *faces, const uint32_t *prefix,
-                                                        const double *cond, const double *g, const double *halo,
-                                                        double *values, double *rhs)
+// that consecutive lanes write consecutive entries.  A wavefront takes U groups of faces at a time (a group: one face of
+// 7 fbs^2 <= 112 entries, or 64 / (7 fbs^2) whole faces for fbs <= 2); everything is unrolled over the U groups, so that
+// their 16-byte descriptors, then their gathers from the packed records, are in flight together: the kernel is a chain
+// of three dependent memory round trips (descriptor, record entries, store) and lives on how many of them overlap
+// (one group at a time: 1.8 ms for the 132 M entries of the 1024^2 k = 2 system).
+template <int FBS, int U>
+__global__ __launch_bounds__(256) void cond_fill_kernel(uint32_t nown, const CondFaceLean *__restrict__ lean,
+                                                        const uint32_t *__restrict__ prefix, const double *__restrict__ cond,
+                                                        const double *__restrict__ halo, double *__restrict__ values)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t per_face = 7u * fbs * fbs;
-    const uint32_t q = (uint32_t)(t / per_face);
+    constexpr uint32_t per_face = 7u * FBS * FBS;
+    constexpr uint32_t FPW = per_face <= 32 ? 64u / per_face : 1u;
+    constexpr uint32_t PASSES = (per_face + 63u) / 64u;
+    constexpr int nf = 4 * FBS, ncond = nf * (nf + 1) / 2 + nf, hd = FBS * (nf + 1);
+    const uint32_t lane = threadIdx.x % 64u, wave = blockIdx.x * (256u / 64u) + threadIdx.x / 64u;
+    const uint32_t sub = FPW > 1 ? lane / per_face : 0u;
+    const uint32_t e0 = FPW > 1 ? lane - sub * per_face : lane;
+    CondFaceLean d[U];
+    uint32_t pre[U];
+    bool on[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t q = (wave * U + u) * FPW + sub;
+        on[u] = q < nown && sub < FPW;
+        const uint32_t qq = on[u] ? q : 0u;
+        d[u] = lean[qq];
+        pre[u] = prefix[qq];
+    }
+    const double *pa_[U][PASSES], *pb_[U][PASSES];
+    size_t out[U][PASSES];
+    bool ok[U][PASSES], two[U][PASSES];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t ncol = (uint32_t)(d[u].packed >> 46) & 7u, rows = (uint32_t)(d[u].packed >> 42) & 15u;
+        const uint32_t rowlen = ncol * FBS;
+#pragma unroll
+        for (uint32_t p = 0; p < PASSES; ++p) {
+            const uint32_t e = e0 + 64u * p;
+            ok[u][p] = on[u] && e < rowlen * FBS;
+            const uint32_t k = (e >= rowlen) + (e >= 2 * rowlen) + (e >= 3 * rowlen);
+            const uint32_t er = ok[u][p] ? e - k * rowlen : 0u;
+            const uint32_t s = er / (uint32_t)FBS, kp = er % (uint32_t)FBS;
+            const uint32_t code = (uint32_t)(d[u].packed >> (6 * s)) & 63u;
+            const int rowA = (int)((rows & 3u) * FBS + k), rowB = (int)(((rows >> 2) & 3u) * FBS + k);
+            const int colA = (int)((code & 3u) * FBS + kp), colB = (int)(((code >> 3) & 3u) * FBS + kp);
+            const bool hasA = code & 4u, hasB = code & 32u;
+            const int aA = rowA < colA ? rowA : colA, bA = rowA < colA ? colA : rowA;
+            const int aB = rowB < colB ? rowB : colB, bB = rowB < colB ? colB : rowB;
+            const double *pA = d[u].cA >= 0 ? cond + (size_t)d[u].cA * ncond + (bA * (bA + 1) / 2 + aA)
+                                            : halo + (size_t)(d[u].cA <= -2 ? -2 - d[u].cA : 0) * hd + (k * nf + colA);
+            const double *pB = cond + (size_t)(d[u].cB >= 0 ? d[u].cB : 0) * ncond + (bB * (bB + 1) / 2 + aB);
+            // one or two addends; a lane without work re-reads entry 0 of the records (never stored)
+            const bool useA = ok[u][p] && hasA, useB = ok[u][p] && hasB;
+            pa_[u][p] = useA ? pA : (useB ? pB : cond);
+            pb_[u][p] = useB ? pB : cond;
+            two[u][p] = useA && useB;
+            out[u][p] = (size_t)pre[u] * (FBS * FBS) + e;
+        }
+    }
+    double va[U][PASSES], vb[U][PASSES];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (uint32_t p = 0; p < PASSES; ++p) { va[u][p] = *pa_[u][p]; vb[u][p] = *pb_[u][p]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (uint32_t p = 0; p < PASSES; ++p)
+            if (ok[u][p]) values[out[u][p]] = two[u][p] ? va[u][p] + vb[u][p] : va[u][p];
+}
+
+// right-hand side of the owned rows: one thread per (owned face, row k)
+__global__ __launch_bounds__(256) void cond_rhs_rows_kernel(CondMesh m, uint32_t nown, int fbs, const CondFaceLean *lean,
+                                                            const double *cond, const double *g, const double *halo, double *rhs)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = t / (uint32_t)fbs;
     if (q >= nown) return;
-    const uint32_t e = (uint32_t)(t % per_face);
-    const CondFace &r = faces[q];
-    const uint32_t rowlen = (uint32_t)r.ncol * fbs;
-    if (e >= rowlen * fbs) return;
-    const int k = (int)(e / rowlen), s = (int)((e % rowlen) / fbs), kp = (int)(e % fbs);
+    const int k = (int)(t % (uint32_t)fbs);
+    const CondFaceLean r = lean[q];
+    const uint32_t rows = (uint32_t)(r.packed >> 42) & 15u;
     const int nf = 4 * fbs, ncond = nf * (nf + 1) / 2 + nf, hd = fbs * (nf + 1);
-    const int rowA = (r.rows & 3) * fbs + k, rowB = ((r.rows >> 2) & 3) * fbs + k;
-    const uint8_t code = r.code[s];
-    const double *recA = r.cA >= 0 ? cond + (size_t)r.cA * ncond : nullptr;
-    const double *recB = r.cB >= 0 ? cond + (size_t)r.cB * ncond : nullptr;
-    const double *hA = r.cA <= -2 ? halo + (size_t)(-2 - r.cA) * hd : nullptr;
-    double v = 0.0;
-    if (code & 4) {
-        const int col = (code & 3) * fbs + kp;
-        v = recA ? cond_S(recA, rowA, col) : hA[k * nf + col];
-    }
-    if (code & 32) {
-        const double w = cond_S(recB, rowB, ((code >> 3) & 3) * fbs + kp);
-        v = (code & 4) ? v + w : w;
-    }
-    values[(size_t)prefix[q] * fbs * fbs + e] = v;
-    if (s == 0 && kp == 0 && rhs != nullptr) {
-        double b = 0.0;
-        bool have = false;
-        if (r.cA >= 0) { b = cond_rhs_contrib(m, recA, r.cA, rowA, fbs, g); have = true; }
-        else if (r.cA <= -2) { b = hA[fbs * nf + k]; have = true; }
-        if (r.cB >= 0) { const double w = cond_rhs_contrib(m, recB, r.cB, rowB, fbs, g); b = have ? b + w : w; }
-        rhs[(size_t)q * fbs + k] = b;
-    }
+    const int rowA = (int)(rows & 3u) * fbs + k, rowB = (int)((rows >> 2) & 3u) * fbs + k;
+    double b = 0.0;
+    bool have = false;
+    if (r.cA >= 0) { b = cond_rhs_contrib(m, cond + (size_t)r.cA * ncond, r.cA, rowA, fbs, g); have = true; }
+    else if (r.cA <= -2) { b = halo[(size_t)(-2 - r.cA) * hd + fbs * nf + k]; have = true; }
+    if (r.cB >= 0) { const double w = cond_rhs_contrib(m, cond + (size_t)r.cB * ncond, r.cB, rowB, fbs, g); b = have ? b + w : w; }
+    rhs[t] = b;
 }
 
 // the rows of the top faces of the slab's top cell row, for the slab above: fbs x nf values, then fbs rhs values
@@ -282,14 +337,15 @@ __global__ __launch_bounds__(256) void condensed_expand_kernel(size_t ncells_loc
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256 ? (n + 255) / 256 : 1); }
 
 hipError_t cond_build_tables(hipStream_t stream, CondMesh m, uint32_t nfaces_local, uint32_t ncells, uint32_t owned_range,
-                             int32_t p0, uint32_t nown, int32_t *adj, CondFace *faces, uint32_t *ncols, uint32_t *prefix)
+                             int32_t p0, uint32_t nown, int32_t *adj, CondFace *faces, CondFaceLean *lean, uint32_t *ncols,
+                             uint32_t *prefix)
 {
     hipLaunchKernelGGL(cond_adj_init_kernel, dim3(blocks_for(nfaces_local)), dim3(256), 0, stream, nfaces_local, adj);
     hipLaunchKernelGGL(cond_adj_cells_kernel, dim3(blocks_for((size_t)4 * ncells)), dim3(256), 0, stream, ncells, m.cell_faces, adj);
     hipError_t e = hipMemsetAsync(ncols, 0, ((size_t)nown + 1) * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     m.adj = adj;
-    hipLaunchKernelGGL(cond_symbolic_kernel, dim3(blocks_for(owned_range)), dim3(256), 0, stream, m, owned_range, p0, nown, faces, ncols);
+    hipLaunchKernelGGL(cond_symbolic_kernel, dim3(blocks_for(owned_range)), dim3(256), 0, stream, m, owned_range, p0, nown, faces, lean, ncols);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t tmp_bytes = 0;
@@ -312,12 +368,28 @@ hipError_t cond_pattern(hipStream_t stream, uint32_t nown, int fbs, const CondFa
     return hipGetLastError();
 }
 
-hipError_t cond_fill(hipStream_t stream, const CondMesh &m, uint32_t nown, int fbs, const CondFace *faces, const uint32_t *prefix,
+#ifndef PA_FILL_UNROLL
+#define PA_FILL_UNROLL 4
+#endif
+hipError_t cond_fill(hipStream_t stream, const CondMesh &m, uint32_t nown, int fbs, const CondFaceLean *lean, const uint32_t *prefix,
                      const double *cond, const double *g, const double *halo, double *values, double *rhs)
 {
     if (nown == 0) return hipSuccess;
-    hipLaunchKernelGGL(cond_fill_kernel, dim3(blocks_for((size_t)nown * 7 * fbs * fbs)), dim3(256), 0, stream, m, nown, fbs, faces, prefix,
-                       cond, g, halo, values, rhs);
+    constexpr int U = PA_FILL_UNROLL;
+    const uint32_t per_face = 7u * fbs * fbs, fpw = per_face <= 32 ? 64u / per_face : 1u;
+    const uint32_t faces_per_block = 4u * U * fpw;
+    const dim3 grid((nown + faces_per_block - 1) / faces_per_block), block(256);
+    const double *h = halo ? halo : cond;
+    switch (fbs) {
+    case 1: hipLaunchKernelGGL((cond_fill_kernel<1, U>), grid, block, 0, stream, nown, lean, prefix, cond, h, values); break;
+    case 2: hipLaunchKernelGGL((cond_fill_kernel<2, U>), grid, block, 0, stream, nown, lean, prefix, cond, h, values); break;
+    case 3: hipLaunchKernelGGL((cond_fill_kernel<3, U>), grid, block, 0, stream, nown, lean, prefix, cond, h, values); break;
+    case 4: hipLaunchKernelGGL((cond_fill_kernel<4, U>), grid, block, 0, stream, nown, lean, prefix, cond, h, values); break;
+    default: return hipErrorInvalidValue;
+    }
+    if (rhs != nullptr)
+        hipLaunchKernelGGL(cond_rhs_rows_kernel, dim3(blocks_for((size_t)nown * fbs)), dim3(256), 0, stream, m, nown, fbs, lean, cond, g,
+                           h, rhs);
     return hipGetLastError();
 }
 

@@ -28,11 +28,19 @@ struct CondFace {
     uint32_t face;           // local face index
 };
 
+// the part of it the numeric phase reads, one 16-byte load: bits 6s .. 6s+5 of `packed`: code[s]; bits 42-45: rows;
+// bits 46-48: ncol
+struct alignas(16) CondFaceLean {
+    int32_t cA, cB;
+    uint64_t packed;
+};
+
 hipError_t cond_build_tables(hipStream_t stream, CondMesh m, uint32_t nfaces_local, uint32_t ncells, uint32_t owned_range,
-                             int32_t p0, uint32_t nown, int32_t *adj, CondFace *faces, uint32_t *ncols, uint32_t *prefix);
+                             int32_t p0, uint32_t nown, int32_t *adj, CondFace *faces, CondFaceLean *lean, uint32_t *ncols,
+                             uint32_t *prefix);
 hipError_t cond_pattern(hipStream_t stream, uint32_t nown, int fbs, const CondFace *faces, const uint32_t *prefix, int64_t *rowptr,
                         int32_t *colind);
-hipError_t cond_fill(hipStream_t stream, const CondMesh &m, uint32_t nown, int fbs, const CondFace *faces, const uint32_t *prefix,
+hipError_t cond_fill(hipStream_t stream, const CondMesh &m, uint32_t nown, int fbs, const CondFaceLean *lean, const uint32_t *prefix,
                      const double *cond, const double *g, const double *halo, double *values, double *rhs);
 hipError_t cond_halo_pack(hipStream_t stream, const CondMesh &m, uint32_t first_cell, uint32_t ncells_row, int fbs, const double *cond,
                           const double *g, double *halo);

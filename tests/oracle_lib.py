@@ -66,7 +66,7 @@ def lib():
     if _LIB is not None:
         return _LIB
     path = os.path.join(ORACLE_DIR, "libhho_oracle.so")
-    srcs = [os.path.join(ORACLE_DIR, n) for n in ("hho_oracle.c", "hho_oracle.h", "cuthho_oracle.c", "cuthho_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, n) for n in ("hho_oracle.c", "hho_oracle.h", "cuthho_oracle.c", "cuthho_oracle.h", "Makefile")]
     if not os.path.exists(path) or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
         build()
     L = C.CDLL(path)
@@ -123,6 +123,14 @@ def lib():
     L.hho_mesh_face_is_boundary.argtypes = [mpp, C.c_size_t, C.c_size_t, C.c_int]
     L.hho_local_ops_batch.argtypes = [dp, u64p, C.c_size_t, C.c_size_t, Degrees, C.c_int, C.c_int,
                                       SCALAR_FN, C.c_void_p, C.c_int, dp, dp, dp, dp, dp]
+    L.hho_max_threads.restype = C.c_int
+    L.hho_local_ops_batch_mt.argtypes = [dp, u64p, C.c_size_t, C.c_size_t, Degrees, C.c_int, C.c_int,
+                                         SCALAR_FN, C.c_void_p, C.c_int, dp, dp, C.c_int]
+    L.hho_matrix_assembly_timed.argtypes = [mpp, C.c_size_t, C.c_size_t, Degrees, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, dp, C.POINTER(C.c_size_t), dp]
+    i32p = C.POINTER(C.c_int32)
+    L.hho_set_from_triplets.restype = C.c_size_t
+    L.hho_set_from_triplets.argtypes = [C.c_size_t, i32p, i32p, dp, C.c_size_t, C.POINTER(C.c_int64), i32p, dp, C.c_int]
     i64p, i32p, u8p = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
     L.hho_assembler_compress_table.restype = C.c_size_t
     L.hho_assembler_compress_table.argtypes = [u8p, C.c_size_t, i64p]
@@ -562,3 +570,35 @@ class CutMesh:
         assert st == 0, st
         k = nt.value
         return tr[:k], tc[:k], tv[:k], rr, rv
+
+
+def max_threads():
+    """OpenMP threads the oracle's multi-threaded loops may use on this host"""
+    return int(lib().hho_max_threads())
+
+
+def matrix_assembly_timed(N, di, quad, stab, rows, rhs_fn=1, bcs_fn=2, rhs_di=0, lo=(0.0, 0.0), hi=(1.0, 1.0), nthreads=1):
+    """The reference's "Matrix assembly" span (cuthho_square.cpp:881-905) on cell rows [rows[0], rows[1]) of the N x N
+    generator mesh -> dict(seconds_ops, seconds_assembly, cells, nnz, checksum)"""
+    mp = MeshParams(N, N, lo[0], hi[0], lo[1], hi[1])
+    sec = (C.c_double * 2)()
+    nnz, cs = C.c_size_t(0), C.c_double(0.0)
+    st = lib().hho_matrix_assembly_timed(C.byref(mp), rows[0], rows[1], di, quad, stab, rhs_fn, bcs_fn, rhs_di, nthreads, sec,
+                                         C.byref(nnz), C.byref(cs))
+    if st not in (0,):
+        raise RuntimeError("hho_matrix_assembly_timed: status %d" % st)
+    return {"seconds_ops": sec[0], "seconds_assembly": sec[1], "cells": (rows[1] - rows[0]) * N, "nnz": nnz.value,
+            "checksum": cs.value}
+
+
+def set_from_triplets(rows, cols, vals, nrows, nthreads=1):
+    rows = np.ascontiguousarray(rows, dtype=np.int32).ravel()
+    cols = np.ascontiguousarray(cols, dtype=np.int32).ravel()
+    vals = np.ascontiguousarray(vals, dtype=np.float64).ravel()
+    rowptr = np.zeros(nrows + 1, dtype=np.int64)
+    colind = np.zeros(max(rows.size, 1), dtype=np.int32)
+    values = np.zeros(max(rows.size, 1))
+    i32p = C.POINTER(C.c_int32)
+    nnz = lib().hho_set_from_triplets(rows.size, rows.ctypes.data_as(i32p), cols.ctypes.data_as(i32p), _dp(vals), nrows,
+                                      rowptr.ctypes.data_as(C.POINTER(C.c_int64)), colind.ctypes.data_as(i32p), _dp(values), nthreads)
+    return rowptr, colind[:nnz], values[:nnz]

@@ -210,40 +210,27 @@ def test_device_conjugated_gradient(asm):
 
 
 def test_multi_gpu_step_in_pieces_equals_whole_mesh(asm):
-    """The N > 1 step of bench.py (row slabs, each processed in pieces: local operators, right-hand sides,
-    packed condensation written into the exchange buffers) run rank after rank on the one GPU gives,
-    cell for cell and bit for bit, what one pass over the whole mesh gives."""
+    """The N > 1 step of bench.py computes a slab's top cell row first (its packed top-face rows travel while the rest
+    is computed) and the slabs rank after rank: cell for cell and bit for bit the records of one pass over the whole mesh."""
     import torch
     import proton_amd as pa
-    from proton_amd.partition import ChunkedExchange, condensed_per_cell, row_partition
-    N, cd, fd, world, chunks = 37, 3, 2, 3, 4
+    from proton_amd.partition import row_partition
+    N, cd, fd, world = 37, 3, 2, 3
     di, _ = pa.degree_info(cd, fd)
-    sz = pa.sizes_for(di, pa.QUAD_TENSOR)
-    nf = 4 * sz.fbs
-    per = condensed_per_cell(sz.fbs, packed=True)
 
-    def condensed(first_row, rows, pieces):
-        asm.generate_mesh(N, N, rows=(first_row, first_row + rows))
-        n_local = asm.ncells
-        lc = torch.empty((n_local, sz.msize, sz.msize), dtype=torch.float64, device=asm.device)
-        rhs = torch.empty((n_local, sz.cbs), dtype=torch.float64, device=asm.device)
-        S = torch.empty((n_local, nf * (nf + 1) // 2), dtype=torch.float64, device=asm.device)
-        g = torch.empty((n_local, nf), dtype=torch.float64, device=asm.device)
-        for (lo, hi) in pieces:
-            first, n = lo * N, (hi - lo) * N
-            asm.ctx.local_ops(di, pa.QUAD_TENSOR, pa.STAB_FANCY, first, n, None, None, None, lc[first:first + n].data_ptr(), None)
-            asm.ctx.cell_rhs(cd, 0, pa.QUAD_TENSOR, pa.capi.FN_SIN_SIN_RHS, first, n, rhs[first:first + n].data_ptr(), None)
-            asm.ctx.static_condensation_packed(di, n, lc[first:first + n].data_ptr(), rhs[first:first + n].data_ptr(),
-                                               S[first:first + n].data_ptr(), g[first:first + n].data_ptr(), None)
+    def records(rows, split_top):
+        asm.generate_mesh(N, N, rows=rows)
+        n = asm.ncells
+        rhs = asm.cell_rhs(cd, pa.capi.FN_SIN_SIN_RHS, pa.QUAD_TENSOR)
+        ci = asm.condensed_info(cd, fd)
+        rec = torch.empty((n, ci.cond_doubles), dtype=torch.float64, device=asm.device)
+        top = N if split_top else 0
+        if top:
+            asm.ctx.condensed_ops(di, pa.QUAD_TENSOR, pa.STAB_FANCY, n - top, top, rhs[n - top:].data_ptr(), rec[n - top:].data_ptr(), None)
+        asm.ctx.condensed_ops(di, pa.QUAD_TENSOR, pa.STAB_FANCY, 0, n - top, rhs.data_ptr(), rec.data_ptr(), None)
         asm.synchronize()
-        return S.cpu(), g.cpu()
+        return rec.cpu()
 
-    whole_S, whole_g = condensed(0, N, [(0, N)])
-    got_S, got_g = [], []
-    for rank in range(world):
-        ex = ChunkedExchange(N, world, rank, per, torch.device("cpu"), chunks)
-        r0, r1 = row_partition(N, world, rank)
-        S, g = condensed(r0, r1 - r0, ex.pieces[rank])
-        assert sum(hi - lo for lo, hi in ex.pieces[rank]) == r1 - r0
-        got_S.append(S); got_g.append(g)
-    assert torch.equal(torch.cat(got_S), whole_S) and torch.equal(torch.cat(got_g), whole_g)
+    whole = records((0, N), False)
+    got = [records(row_partition(N, world, r), True) for r in range(world)]
+    assert torch.equal(torch.cat(got), whole)

@@ -282,3 +282,27 @@ def test_condensed_mode_on_an_uploaded_mesh_and_status_codes(asm, oracle):
     with pytest.raises(ProtonAmdError) as e:
         asm.condensed_csr_fill(cd, fd, rec3, None)
     assert e.value.status == 1
+
+
+def test_rccl_communicator_of_one_rank(asm):
+    """pa_comm_* on the one GPU of the box: RCCL is found and bound at run time, a communicator of one rank comes up on
+    the context's device, the collectives run on its side stream and pa_comm_wait orders the context's stream behind
+    them (all-gather of one rank = a copy, all-reduce = the identity, the halo exchange has no neighbour)."""
+    import torch
+    from proton_amd import capi
+    uid = capi.comm_unique_id()
+    assert len(uid) == capi.COMM_ID_BYTES
+    comm = capi.Comm(asm.ctx, 1, 0, uid)
+    src = torch.arange(1000, dtype=torch.float64, device=asm.device)
+    dst = torch.zeros_like(src)
+    comm.allgather_start(src.data_ptr(), dst.data_ptr(), src.numel() * 8)
+    comm.wait()
+    acc = src.clone()
+    comm.allreduce_sum_start(acc.data_ptr(), acc.numel())
+    comm.wait()
+    comm.halo_exchange_start(src.data_ptr(), 10, dst.data_ptr(), 10)      # rank 0 of 1: nobody above, nobody below
+    comm.wait()
+    asm.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src) and torch.equal(acc, src)
+    comm.close()

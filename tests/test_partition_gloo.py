@@ -1,6 +1,9 @@
-"""N > 1 path on CPU: world_size-2 gloo.  Each rank computes the condensed face blocks of its cell
-rows (with the oracle standing in for the GPU kernels), the exchange gathers them, and the result
-must equal the single-process computation in global cell order."""
+"""N > 1 path on CPU: world_size-2 (and 3) gloo, no GPU.  The cells shard by rows; every rank assembles the rows of the
+face-only system it owns; the one exchange of a step is the packed top-face rows of each slab's top cell row, one slab
+up.  Here the oracle stands in for the GPU kernels (records per cell), numpy for the assembly of a slab, and what is
+under test is the product's HOST logic: the closed-form row partition (pa_condensed_partition_info, the library loads
+without a GPU), the halo layout it announces, and the host-staged twin of pa_comm_halo_exchange_start
+(proton_amd.partition.HostStagedHalo).  The stacked slabs must be the whole-mesh system."""
 import os
 import socket
 
@@ -10,7 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from proton_amd.partition import ChunkedExchange, CondensedExchange, cell_counts, condensed_per_cell, row_partition, unpack_symmetric
+from proton_amd.partition import HostStagedHalo, cell_counts, row_partition
 
 
 def test_row_partition_covers_all_rows():
@@ -24,128 +27,159 @@ def test_row_partition_covers_all_rows():
             assert sum(cell_counts(N, N, world)) == N * N
 
 
-def _condensed_blocks(N, cd, fd, first, n):
+def test_partition_info_matches_the_assemblers_compress_table(oracle):
+    """row ranges of the slabs from the closed forms == positions in the reference's compress table (hho.hpp:305-323)"""
+    from proton_amd import capi
+    for N, world, fd in ((5, 2, 1), (7, 3, 2), (8, 8, 0), (6, 4, 3)):
+        mp_, points, ptids = oracle.make_mesh(N, N)
+        ref = oracle.Assembler(mp_, points, ptids, oracle.degrees(fd + 1, fd))
+        di, _ = capi.degree_info(fd + 1, fd)
+        fbs, face_row = fd + 1, 2 * N + 1
+        end = 0
+        for r in range(world):
+            r0, r1 = row_partition(N, world, r)
+            info = capi.condensed_partition_info(N, N, (r0, r1), di)
+            own = [f for f in range(r0 * face_row, min(r1 * face_row, ref.nf)) if not ref.is_dir[f]]
+            assert info.num_other_faces == ref.num_other and info.system_size == fbs * ref.num_other
+            assert info.row_begin == end and info.row_end == end + fbs * len(own)
+            if own:
+                assert info.row_begin == fbs * ref.compress[own[0]] and info.row_end == fbs * (ref.compress[own[-1]] + 1)
+            assert info.halo_cells == (N if r1 < N else 0) and bool(info.has_below) == (r0 > 0)
+            assert info.halo_doubles == fbs * (4 * fbs + 1) and info.nf == 4 * fbs
+            end = info.row_end
+        assert end == fbs * ref.num_other
+
+
+def _slab(N, cd, fd, r0, r1):
+    """records of the slab's cells by the oracle: S [n, nf, nf], g [n, nf]; plus the assembler of the whole mesh"""
     import oracle_lib as o
     mp_, points, ptids = o.make_mesh(N, N)
     di = o.degrees(cd, fd)
-    st, out = o.local_ops_batch(points, ptids, di, o.QUAD_TENSOR, o.STAB_FANCY, first=first, n=n, fn=1, want=("lc",))
+    n = (r1 - r0) * N
+    st, out = o.local_ops_batch(points, ptids, di, o.QUAD_TENSOR, o.STAB_FANCY, first=r0 * N, n=n, fn=1, want=("lc",))
     assert st == 0
     nf = 4 * di.fbs
-    Sb, gb = np.zeros((n, nf, nf)), np.zeros((n, nf))
+    S, g = np.zeros((n, nf, nf)), np.zeros((n, nf))
     for c in range(n):
-        st, S, g, rec = o.static_condensation(out["lc"][c], out["rhs"][c], di.cbs)
-        Sb[c] = S.T                                  # column-major, as the device kernel writes it
-        gb[c] = g
-    return Sb, gb
+        st, S[c], g[c], rec = o.static_condensation(out["lc"][c], out["rhs"][c], di.cbs)
+    return S, g, o.Assembler(mp_, points, ptids, di, bf_id=2), di
 
 
-def _worker(rank, world, port, N, cd, fd, q, packed=False):
+def _cell_rows(ref, di, c, S, g):
+    """assembler::assemble on the condensed block of global cell c -> (rows, cols, vals) kept triplets and rhs (rows, vals)"""
+    fbs, nf = di.fbs, 4 * di.fbs
+    idx, dd = np.zeros(nf, dtype=np.int64), np.zeros(nf)
+    for lf in range(4):
+        f = int(ref.cell_faces[c, lf])
+        for k in range(fbs):
+            idx[lf * fbs + k] = -1 if ref.is_dir[f] else ref.compress[f] * fbs + k
+            dd[lf * fbs + k] = ref.g[f, k] if ref.is_dir[f] else 0.0
+    keep = idx >= 0
+    rr, cc = np.meshgrid(idx, idx, indexing="ij")
+    m = keep[:, None] & keep[None, :]
+    b = g - S[:, ~keep] @ dd[~keep]
+    return rr[m], cc[m], S[m], idx[keep], b[keep]
+
+
+def _pack_halo(ref, di, N, r1, S, g):
+    """the layout pa_condensed_halo_pack announces: per cell of the slab's top row fbs x nf values S(2 fbs + k, :), then
+    the fbs right-hand-side contributions with the Dirichlet columns already moved over"""
+    fbs, nf = di.fbs, 4 * di.fbs
+    out = np.zeros((N, fbs * (nf + 1)))
+    for i in range(N):
+        c = (r1 - 1) * N + i
+        loc = S.shape[0] - N + i
+        dd = np.zeros(nf)
+        dirichlet = np.zeros(nf, dtype=bool)
+        for lf in range(4):
+            f = int(ref.cell_faces[c, lf])
+            if ref.is_dir[f]:
+                dirichlet[lf * fbs:(lf + 1) * fbs] = True
+                dd[lf * fbs:(lf + 1) * fbs] = ref.g[f]
+        rows = slice(2 * fbs, 3 * fbs)
+        out[i, :fbs * nf] = S[loc, rows, :].reshape(-1)
+        out[i, fbs * nf:] = g[loc, rows] - S[loc, rows][:, dirichlet] @ dd[dirichlet]
+    return out
+
+
+def _assemble_owned(ref, di, N, r0, r1, info, S, g, halo):
+    """dense owned rows x all columns of the face-only system, and their right-hand side"""
+    fbs, nf = di.fbs, 4 * di.fbs
+    nrows = info.row_end - info.row_begin
+    A, b = np.zeros((nrows, info.system_size)), np.zeros(nrows)
+    own = lambda r: (r >= info.row_begin) & (r < info.row_end)  # noqa: E731
+    for cl in range(S.shape[0]):
+        rr, cc, vv, br, bv = _cell_rows(ref, di, r0 * N + cl, S[cl], g[cl])
+        m = own(rr)
+        np.add.at(A, (rr[m] - info.row_begin, cc[m]), vv[m])
+        mb = own(br)
+        np.add.at(b, br[mb] - info.row_begin, bv[mb])
+    if halo is not None:                     # rows of this slab's bottom faces: the contribution of the cells below
+        for i in range(N):
+            c = (r0 - 1) * N + i
+            top = int(ref.cell_faces[c, 2])
+            assert not ref.is_dir[top]
+            for k in range(fbs):
+                row = ref.compress[top] * fbs + k - info.row_begin
+                for lf in range(4):
+                    f = int(ref.cell_faces[c, lf])
+                    if ref.is_dir[f]:
+                        continue
+                    for kp in range(fbs):
+                        A[row, ref.compress[f] * fbs + kp] += halo[i, k * nf + lf * fbs + kp]
+                b[row] += halo[i, fbs * nf + k]
+    return A, b
+
+
+def _worker(rank, world, port, N, cd, fd, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        import oracle_lib as o
-        di = o.degrees(cd, fd)
-        per = condensed_per_cell(di.fbs, packed)
-        counts = cell_counts(N, N, world)
+        from proton_amd import capi
         r0, r1 = row_partition(N, world, rank)
-        ex = CondensedExchange(counts, per, rank, torch.device("cpu"))
-        nf = 4 * di.fbs
-        Sb, gb = _condensed_blocks(N, cd, fd, r0 * N, (r1 - r0) * N)
-        S_view, g_view = ex.local_S_g(nf)
-        if packed:                                   # upper triangle, column-packed: the bench's exchange format
-            iu = np.triu_indices(nf)
-            Sp = np.zeros((Sb.shape[0], nf * (nf + 1) // 2))
-            Sp[:, iu[1] * (iu[1] + 1) // 2 + iu[0]] = Sb[:, iu[1], iu[0]]      # Sb is column-major: Sb[c, j, i] = S(i, j)
-            S_view.copy_(torch.from_numpy(Sp))
-        else:
-            S_view.copy_(torch.from_numpy(Sb))
-        g_view.copy_(torch.from_numpy(gb))
+        S, g, ref, di = _slab(N, cd, fd, r0, r1)
+        pdi, _ = capi.degree_info(cd, fd)
+        info = capi.condensed_partition_info(N, N, (r0, r1), pdi)
+        send = torch.from_numpy(_pack_halo(ref, di, N, r1, S, g)) if info.halo_cells else None
+        recv = torch.zeros((N, info.halo_doubles), dtype=torch.float64) if info.has_below else None
+        if send is not None:
+            assert tuple(send.shape) == (info.halo_cells, info.halo_doubles)
         dist.barrier()
-        ex.exchange()
-        parts = [ex.gathered_S_g(r, nf)[0] for r in range(world)]
-        if packed:
-            parts = [unpack_symmetric(p_, nf) for p_ in parts]
-        fullS = torch.cat(parts, dim=0).numpy()
-        fullg = torch.cat([ex.gathered_S_g(r, nf)[1] for r in range(world)], dim=0).numpy()
-        q.put((rank, (fullS, fullg)))
+        HostStagedHalo(rank, world)(send, recv)
+        A, b = _assemble_owned(ref, di, N, r0, r1, info, S, g, None if recv is None else recv.numpy())
+        q.put((rank, (int(info.row_begin), A, b)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N,cd,fd,packed", [(6, 2, 1, False), (5, 3, 2, False), (5, 3, 2, True), (7, 0, 1, True)])
-def test_two_rank_exchange_matches_single_process(N, cd, fd, packed):
+@pytest.mark.parametrize("N,cd,fd,world", [(6, 2, 1, 2), (5, 3, 2, 2), (7, 0, 1, 3)])
+def test_slabs_with_halo_exchange_equal_the_whole_system(N, cd, fd, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    world = 2
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, cd, fd, q, packed)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, cd, fd, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=120) for _ in range(world))
+    results = dict(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    refS, refg = _condensed_blocks(N, cd, fd, 0, N * N)
-    iu = np.triu_indices(refS.shape[1])
+    # the whole mesh in one process
+    S, g, ref, di = _slab(N, cd, fd, 0, N)
+    from proton_amd import capi
+    pdi, _ = capi.degree_info(cd, fd)
+    info = capi.condensed_partition_info(N, N, (0, N), pdi)
+    A, b = _assemble_owned(ref, di, N, 0, N, info, S, g, None)
+    assert A.shape[0] == info.system_size and abs(A - A.T).max() < 1e-12 * abs(A).max()
+    row = 0
     for r in range(world):
-        if packed:                                       # the upper triangle travels, the lower one is its mirror
-            assert np.array_equal(results[r][0][:, iu[0], iu[1]], refS[:, iu[1], iu[0]])
-            assert np.array_equal(results[r][0], results[r][0].transpose(0, 2, 1))
-        else:
-            assert np.array_equal(results[r][0], refS)   # every rank holds the full set, in global cell order
-        assert np.array_equal(results[r][1], refg)
-
-
-def _chunk_worker(rank, world, port, N, cd, fd, chunks, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        import oracle_lib as o
-        di = o.degrees(cd, fd)
-        nf = 4 * di.fbs
-        ex = ChunkedExchange(N, world, rank, condensed_per_cell(di.fbs), torch.device("cpu"), chunks)
-        r0, r1 = row_partition(N, world, rank)
-        covered = 0
-        for k in range(ex.chunks):                       # the bench's loop: piece k computed, its gather started
-            first, n = ex.piece_cells(k)
-            assert first == covered
-            covered += n
-            Sb, gb = _condensed_blocks(N, cd, fd, r0 * N + first, n)
-            S_view, g_view = ex.local_S_g(k, nf)
-            S_view.copy_(torch.from_numpy(Sb))
-            g_view.copy_(torch.from_numpy(gb))
-            ex.exchange_async(k)
-        assert covered == (r1 - r0) * N
-        ex.wait()
-        fullS = torch.cat([ex.gathered_S_g(r, nf)[0] for r in range(world)], dim=0).numpy()
-        fullg = torch.cat([ex.gathered_S_g(r, nf)[1] for r in range(world)], dim=0).numpy()
-        q.put((rank, (fullS, fullg)))
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("N,chunks", [(7, 3), (5, 8)])
-def test_chunked_overlapped_exchange_matches_single_process(N, chunks):
-    """the N > 1 step of bench.py: pieces of the local rows, asynchronous all_gather per piece (uneven pieces,
-    more pieces asked for than rows available)"""
-    cd, fd = 2, 1
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    world = 2
-    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, N, cd, fd, chunks, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = dict(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    refS, refg = _condensed_blocks(N, cd, fd, 0, N * N)
-    for r in range(world):
-        assert np.array_equal(results[r][0], refS) and np.array_equal(results[r][1], refg)
+        begin, Ar, br = results[r]
+        assert begin == row
+        # the same sums of the same two addends: equal up to the order of the additions of a shared face's two cells
+        assert np.abs(Ar - A[row:row + Ar.shape[0]]).max() <= 1e-15 * np.abs(A).max()
+        assert np.abs(br - b[row:row + Ar.shape[0]]).max() <= 1e-15 * max(1.0, np.abs(b).max())
+        row += Ar.shape[0]
+    assert row == info.system_size
