@@ -172,9 +172,13 @@ struct Cfg {
     // without spills beat 3 with), the others fit 3 waves/SIMD
     // (the dense fancy form carries the mass factor and the dense T_F as well: one step lower, or it spills by the hundred)
     static constexpr bool DENSE_FANCY = STAB_ == STAB_FANCY && CD_ != FD_ + 1;
+#ifdef PA_WAVES_OVERRIDE      /* A/B builds: beats the per-instance setting of _build.py */
+    static constexpr int WAVES_LC = PA_WAVES_OVERRIDE;
+#else
     static constexpr int WAVES_LC = PA_WAVES_PER_EU ? PA_WAVES_PER_EU
                                  : DENSE_FANCY ? ((MS > 24 || RBS > 10) ? 1 : (MS > 16 || RBS > 6) ? 2 : 3)
                                                : ((MS > 24 || RBS > 10) ? 2 : 3);
+#endif
     static constexpr int WAVES = (COND_ != 0 && PA_COND_WAVES_PER_EU) ? PA_COND_WAVES_PER_EU : WAVES_LC;
     static constexpr bool HAS_STAB = STAB != STAB_NONE;
     // lc-only path: accumulators -> HBM directly (no LDS image) where the matrix is big enough for the

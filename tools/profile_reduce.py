@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Reduce rocprofv3 counter_collection CSVs (separate --pmc passes) to per-kernel, per-dispatch means for every pa::
+kernel; FETCH/WRITE in bytes with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half the bytes of a
+wide streaming read: doubled; both counters are in KiB).   profile_reduce.py <dir> <workload> <mode> [bench.json]"""
+import collections, csv, glob, json, sys
+d, workload, mode = sys.argv[1], sys.argv[2], sys.argv[3]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True):
+    per = collections.defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "pa::" not in k:
+            continue
+        per[(k, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+    for (k, _, c), v in per.items():
+        acc[k][c].append(v)
+out = {"workload": workload, "mode": mode, "kernels": {}}
+dominant = 0.0
+for k, cs in sorted(acc.items()):
+    m = {c: sum(v) / len(v) for c, v in cs.items()}
+    rec = {"dispatches": max(len(v) for v in cs.values()), "per_dispatch_means": m}
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        rec["FETCH_SIZE_bytes"] = m["FETCH_SIZE"] * 1024
+        rec["WRITE_SIZE_bytes"] = m["WRITE_SIZE"] * 1024
+        rec["hbm_bytes_per_launch_gfx950_corrected"] = 2 * rec["FETCH_SIZE_bytes"] + rec["WRITE_SIZE_bytes"]
+        if "hho_local_ops_kernel" in k or "hho_cell_pre_kernel" in k:
+            dominant += rec["hbm_bytes_per_launch_gfx950_corrected"]
+    if "SQ_LDS_BANK_CONFLICT" in m and m.get("SQ_LDS_IDX_ACTIVE"):
+        rec["lds_bank_conflict_frac"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]
+    if "SQ_WAVE_CYCLES" in m and "SQ_WAIT_INST_ANY" in m:
+        rec["wave_wait_frac"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
+    out["kernels"][k[:110]] = rec
+out["hbm_bytes_per_launch_dominant_kernel"] = dominant     # pre-pass + cooperative kernel of one step
+if len(sys.argv) > 4:
+    try:
+        b = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+        out["bench_kernel_ms_under_profiler"] = b["roofline"]["kernel_ms"]
+        out["algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes_per_cell"] * b["roofline"]["cells_per_launch"]
+    except Exception as e:      # noqa: BLE001
+        out["bench_line_error"] = str(e)
+out["notes"] = ("separate rocprofv3 --pmc passes with --kernel-trace only; FETCH_SIZE / WRITE_SIZE in KiB; FETCH doubled per "
+                "MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B); SQ_* cycle counters in quad-cycles except "
+                "SQ_LDS_IDX_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES")
+print(json.dumps(out, indent=1))
