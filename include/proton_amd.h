@@ -92,6 +92,11 @@ int pa_context_synchronize(pa_context *ctx);
  * room: next to the persistent local-operator grid of a 512^2 mesh it measured 8 % slower than the plain sequence.) */
 int pa_context_set_cut_overlap(pa_context *ctx, int on);
 const char *pa_last_error(pa_context *ctx);      /* text of the last HIP failure, "" if none  */
+/* The record buffer of the local-operator calls (see pa_local_ops_batch) grows on demand up to a cap -- 4 GiB unless
+ * pa_context_set_record_cap says otherwise (>= 1 MiB; larger ranges of cells run in equal pieces) -- and stays with the
+ * context for reuse.  pa_context_trim waits for the context's stream and gives it back to the device. */
+int pa_context_set_record_cap(pa_context *ctx, size_t bytes);
+int pa_context_trim(pa_context *ctx);
 int pa_abi_version(void);
 
 /* device-memory helpers so a non-torch host (the C++ header, a cgo/JNI caller) needs no HIP */
@@ -130,7 +135,7 @@ int pa_mesh_counts(pa_context *ctx, size_t *npoints, size_t *ncells);
  *   factorization of the fancy stabilization).
  * Asynchronous on the context's stream.  Two kernels per call: a one-thread-per-cell pre-pass and the
  * cooperative kernel, which meet in a record buffer the CONTEXT owns (grown on demand, at most 4 GiB --
- * PA_PRE_BYTES overrides -- larger ranges run in equal pieces; freed by pa_context_destroy).  Calls on one
+ * pa_context_set_record_cap -- larger ranges run in equal pieces; released by pa_context_trim / pa_context_destroy).  Calls on one
  * context are serialized by its stream, so the buffer needs no locking; use one context per stream. */
 int pa_local_ops_batch(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind,
                        size_t first, size_t n,

@@ -22,6 +22,8 @@ OBJ_DIR = os.path.join(_OUT, "obj")
 LIB_PATH = os.path.join(_OUT, "libproton_amd.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+if _TAG:                                    # tuning builds read the profiling knobs (PA_ABLATE, PA_BLOCKS_PER_CU, PA_LANES_PER_CELL)
+    FLAGS.append("-DPA_TUNING=1")
 if os.environ.get("PA_EXTRA_FLAGS"):        # experiments: extra compiler flags, e.g. "-mllvm -amdgpu-use-amdgpu-trackers"
     FLAGS.extend(os.environ["PA_EXTRA_FLAGS"].split())
 if os.environ.get("PA_WAVES_PER_EU"):      # tuning knob: register budget of the local-operator kernel

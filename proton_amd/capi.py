@@ -20,6 +20,7 @@ STATUS = {0: "PA_OK", 1: "PA_ERR_INVALID_ARG", 2: "PA_ERR_INVALID_DEGREE", 3: "P
 EXPORTS = [
     "pa_abi_version", "pa_degree_info_equal", "pa_degree_info_make", "pa_sizes_for",
     "pa_context_create", "pa_context_destroy", "pa_context_synchronize", "pa_context_set_cut_overlap", "pa_last_error",
+    "pa_context_trim", "pa_context_set_record_cap",
     "pa_malloc", "pa_free", "pa_memcpy_h2d", "pa_memcpy_d2h", "pa_memset",
     "pa_mesh_upload", "pa_mesh_attach_device", "pa_mesh_generate", "pa_mesh_counts",
     "pa_local_ops_batch", "pa_cell_rhs_batch", "pa_cell_quadrature_points",
@@ -117,6 +118,8 @@ def lib():
     L.pa_context_destroy.argtypes = [vp]
     L.pa_context_synchronize.argtypes = [vp]
     L.pa_context_set_cut_overlap.argtypes = [vp, C.c_int]
+    L.pa_context_trim.argtypes = [vp]
+    L.pa_context_set_record_cap.argtypes = [vp, sz]
     L.pa_last_error.argtypes = [vp]
     L.pa_last_error.restype = C.c_char_p
     L.pa_malloc.argtypes = [vp, sz, C.POINTER(vp)]
@@ -293,6 +296,12 @@ class Context:
 
     def synchronize(self):
         self._ck(self._L.pa_context_synchronize(self.h), "pa_context_synchronize")
+
+    def trim(self):
+        self._ck(self._L.pa_context_trim(self.h), "pa_context_trim")
+
+    def set_record_cap(self, nbytes):
+        self._ck(self._L.pa_context_set_record_cap(self.h, nbytes), "pa_context_set_record_cap")
 
     def set_cut_overlap(self, on):
         self._ck(self._L.pa_context_set_cut_overlap(self.h, 1 if on else 0), "pa_context_set_cut_overlap")

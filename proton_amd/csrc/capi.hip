@@ -115,6 +115,7 @@ struct pa_context {
     // records of the per-cell pre-pass (hho_pre.hpp), grown on demand, reused by every local-operator call
     double *d_pre = nullptr;
     size_t pre_capacity = 0;                  // doubles
+    size_t pre_cap_bytes = (size_t)4 << 30;   // pa_context_set_record_cap
     // pa_context_set_cut_overlap: the cut-cell kernel runs on a side stream next to the uncut cells' kernels
     hipStream_t side = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
@@ -279,6 +280,7 @@ int pa_context_destroy(pa_context *ctx)
 {
     if (!ctx) return PA_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
+    (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     release_mesh(ctx);
@@ -295,14 +297,33 @@ int pa_context_destroy(pa_context *ctx)
 int pa_context_synchronize(pa_context *ctx)
 {
     if (!ctx) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (ctx->side) { PA_HIP(ctx, hipStreamSynchronize(ctx->side)); ctx->side_pending = false; }
     PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PA_OK;
+}
+
+int pa_context_trim(pa_context *ctx)
+{
+    if (!ctx) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_pre) (void)hipFree(ctx->d_pre);
+    ctx->d_pre = nullptr; ctx->pre_capacity = 0;
+    return PA_OK;
+}
+
+int pa_context_set_record_cap(pa_context *ctx, size_t bytes)
+{
+    if (!ctx || bytes < ((size_t)1 << 20)) return PA_ERR_INVALID_ARG;
+    ctx->pre_cap_bytes = bytes;
     return PA_OK;
 }
 
 int pa_context_set_cut_overlap(pa_context *ctx, int on)
 {
     if (!ctx) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     (void)hipSetDevice(ctx->device);
     if (on && !ctx->side) {
         PA_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
@@ -322,6 +343,7 @@ const char *pa_last_error(pa_context *ctx) { return ctx ? ctx->last_error.c_str(
 int pa_malloc(pa_context *ctx, size_t bytes, void **d_out)
 {
     if (!ctx || !d_out) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     PA_HIP(ctx, hipSetDevice(ctx->device));
     PA_HIP(ctx, hipMalloc(d_out, bytes ? bytes : 1));
     return PA_OK;
@@ -330,6 +352,7 @@ int pa_malloc(pa_context *ctx, size_t bytes, void **d_out)
 int pa_free(pa_context *ctx, void *d_ptr)
 {
     if (!ctx) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (d_ptr) PA_HIP(ctx, hipFree(d_ptr));
     return PA_OK;
 }
@@ -337,6 +360,7 @@ int pa_free(pa_context *ctx, void *d_ptr)
 int pa_memcpy_h2d(pa_context *ctx, void *d_dst, const void *src, size_t bytes)
 {
     if (!ctx || (!d_dst && bytes) || (!src && bytes)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     PA_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PA_OK;
@@ -345,6 +369,7 @@ int pa_memcpy_h2d(pa_context *ctx, void *d_dst, const void *src, size_t bytes)
 int pa_memcpy_d2h(pa_context *ctx, void *dst, const void *d_src, size_t bytes)
 {
     if (!ctx || (!dst && bytes) || (!d_src && bytes)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     PA_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PA_OK;
@@ -353,6 +378,7 @@ int pa_memcpy_d2h(pa_context *ctx, void *dst, const void *d_src, size_t bytes)
 int pa_memset(pa_context *ctx, void *d_dst, int value, size_t bytes)
 {
     if (!ctx || (!d_dst && bytes)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     PA_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
     return PA_OK;
 }
@@ -361,6 +387,7 @@ int pa_memset(pa_context *ctx, void *d_dst, int value, size_t bytes)
 int pa_mesh_upload(pa_context *ctx, const double *points, size_t npoints, const uint32_t *cell_ptids, size_t ncells)
 {
     if (!ctx || !points || !cell_ptids || npoints == 0) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     for (size_t i = 0; i < 4 * ncells; ++i)
         if (cell_ptids[i] >= npoints) return PA_ERR_INVALID_ARG;      // the kernels gather points[ptid] unchecked
     PA_HIP(ctx, hipSetDevice(ctx->device));
@@ -379,6 +406,7 @@ int pa_mesh_upload(pa_context *ctx, const double *points, size_t npoints, const 
 int pa_mesh_attach_device(pa_context *ctx, const double *d_points, size_t npoints, const uint32_t *d_cell_ptids, size_t ncells)
 {
     if (!ctx || !d_points || !d_cell_ptids || npoints == 0) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     release_mesh(ctx);
     ctx->d_points = const_cast<double *>(d_points);
     ctx->d_ptids = const_cast<uint32_t *>(d_cell_ptids);
@@ -391,6 +419,7 @@ int pa_mesh_generate(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double
                      size_t row_begin, size_t row_end)
 {
     if (!ctx || Nx == 0 || Ny == 0 || row_begin >= row_end || row_end > Ny) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     const size_t rows = row_end - row_begin;
     const size_t np = (Nx + 1) * (rows + 1), nc = Nx * rows;
     if (np >= ((size_t)1 << 32)) return PA_ERR_INVALID_ARG;
@@ -427,6 +456,7 @@ int pa_mesh_set_faces(pa_context *ctx, const uint32_t *cell_faces, const uint32_
                       const uint8_t *face_is_dirichlet, size_t nfaces)
 {
     if (!ctx || !cell_faces || !face_pts || !face_is_dirichlet || nfaces == 0) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->d_points) return PA_ERR_NO_MESH;
     for (size_t i = 0; i < 4 * ctx->ncells; ++i)
         if (cell_faces[i] >= nfaces) return PA_ERR_INVALID_ARG;
@@ -456,6 +486,7 @@ int pa_mesh_set_faces(pa_context *ctx, const uint32_t *cell_faces, const uint32_
 int pa_assembler_query(pa_context *ctx, pa_degree_info di, pa_assembler_info *out)
 {
     if (!ctx || !out || di.cell_deg < 0 || di.face_deg < 0) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
     out->ncells_global = ctx->ncells_global; out->cell_base = ctx->cell_base;
     out->nfaces_local = ctx->nfaces_local; out->face_base = ctx->face_base;
@@ -467,9 +498,11 @@ int pa_assembler_query(pa_context *ctx, pa_degree_info di, pa_assembler_info *ou
 int pa_dirichlet_data_batch(pa_context *ctx, int face_deg, int fn, const double *d_fvals, double *d_g)
 {
     if (!ctx || !d_g || face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
     if (fn < PA_FN_SAMPLED || fn > PA_FN_ONE || (fn == PA_FN_SAMPLED && !d_fvals)) return PA_ERR_INVALID_ARG;
     const uint32_t nf = (uint32_t)ctx->nfaces_local;
+    if (nf == 0) return PA_OK;
     const dim3 grid((nf + 255) / 256), block(256);
 #define PA_DD_CASE(FD)                                                                                              \
     case FD:                                                                                                        \
@@ -485,8 +518,10 @@ int pa_dirichlet_data_batch(pa_context *ctx, int face_deg, int fn, const double 
 int pa_face_quadrature_points(pa_context *ctx, int face_deg, double *d_xyw)
 {
     if (!ctx || !d_xyw || face_deg < 0 || face_deg > 4) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
     const uint32_t nf = (uint32_t)ctx->nfaces_local;
+    if (nf == 0) return PA_OK;
     hipLaunchKernelGGL(pa::face_qpoints_kernel, dim3((nf + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_tab,
                        ctx->d_points, ctx->d_face_pts, nf, face_deg + 1, d_xyw);
     PA_HIP(ctx, hipGetLastError());
@@ -498,6 +533,7 @@ int pa_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n
                       int32_t *d_rhs_rows, double *d_rhs_vals)
 {
     if (!ctx || !d_lc || !d_rows || !d_cols || !d_vals || !d_rhs_rows || !d_rhs_vals) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (di.cell_deg < 0 || di.face_deg < 0 || di.face_deg > 3 || di.cell_deg > 4) return PA_ERR_INVALID_DEGREE;
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
     if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
@@ -524,6 +560,7 @@ static int take_local(pa_context *ctx, pa_degree_info di, size_t first, size_t n
                       const double *d_g, int expanded, double *d_out)
 {
     if (!ctx || !d_solution || !d_out) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (di.cell_deg < 0 || di.face_deg < 0 || di.face_deg > 3 || di.cell_deg > 4) return PA_ERR_INVALID_DEGREE;
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
     if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
@@ -560,6 +597,7 @@ int pa_obstacle_tables(pa_context *ctx, const uint8_t *d_in_A, int32_t *d_A_ct, 
                        size_t *num_A)
 {
     if (!ctx || !d_in_A || !d_A_ct || !d_B_ct) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->d_ptids) return PA_ERR_NO_MESH;
     const uint32_t n = (uint32_t)ctx->ncells;
     const uint32_t nblocks = (n + pa::SCAN_TILE - 1) / pa::SCAN_TILE;
@@ -617,6 +655,7 @@ int pa_obstacle_expand_solution(pa_context *ctx, pa_degree_info di, const double
                                 const int32_t *d_B_ct, size_t num_I, double *d_alpha, double *d_beta)
 {
     if (!ctx || !d_solution || !d_gamma || !d_in_A || !d_A_ct || !d_B_ct || !d_alpha || !d_beta) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (di.cell_deg < 0 || di.face_deg < 0 || di.face_deg > 3 || di.cell_deg > 4) return PA_ERR_INVALID_DEGREE;
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
     if (!whole_mesh(ctx)) { ctx->last_error = "obstacle assembler needs the whole mesh on the context"; return PA_ERR_INVALID_ARG; }
@@ -635,6 +674,7 @@ int pa_csr_from_triplets(pa_context *ctx, size_t nslots, const int32_t *d_rows, 
                          size_t nrows, int64_t *d_rowptr, int32_t *d_colind, double *d_values, size_t *nnz)
 {
     if (!ctx || !d_rowptr || (nslots && (!d_rows || !d_cols || !d_vals || !d_colind || !d_values))) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (nslots >= ((size_t)1 << 31) || nrows >= ((size_t)1 << 31)) return PA_ERR_INVALID_ARG;
     PA_HIP(ctx, pa::csr_from_triplets(ctx->stream, nslots, d_rows, d_cols, d_vals, nrows, d_rowptr, d_colind, d_values, nnz));
     return PA_OK;
@@ -646,6 +686,7 @@ int pa_conjugated_gradient(pa_context *ctx, size_t nrows, const int64_t *d_rowpt
                            double *relative_residual)
 {
     if (!ctx || !d_rowptr || (nrows && (!d_colind || !d_values || !d_b || !d_x))) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     int reason = 0;
     PA_HIP(ctx, pa::conjugated_gradient(ctx->stream, nrows, d_rowptr, d_colind, d_values, d_b, d_x, convergence_threshold,
                                         divergence_threshold, max_iter, apply_preconditioner, &reason, iterations, relative_residual));
@@ -656,6 +697,7 @@ int pa_conjugated_gradient(pa_context *ctx, size_t nrows, const int64_t *d_rowpt
 int pa_mesh_counts(pa_context *ctx, size_t *npoints, size_t *ncells)
 {
     if (!ctx) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (npoints) *npoints = ctx->npoints;
     if (ncells) *ncells = ctx->ncells;
     return PA_OK;
@@ -667,10 +709,12 @@ static int pick_lanes(int cd, int fd, int quad)
     const int gmin = min_lanes(cd, fd, quad);
     if (gmin == 0) return 0;
     int lanes = gmin;                                   // fewest lanes per cell = most cells per wavefront
+#ifdef PA_TUNING      // profiling / A-B builds only (proton_amd/_build.py, PA_BUILD_TAG): the shipped library reads no knob
     if (const char *env = std::getenv("PA_LANES_PER_CELL")) {
         const int v = std::atoi(env);
         if ((v == 16 || v == 32 || v == 64) && v >= gmin) lanes = v;
     }
+#endif
     return lanes;
 }
 
@@ -692,10 +736,12 @@ static int select_kernel(pa_context *ctx, pa_degree_info di, int quad_kind, int 
     // the launch bound allows the hardware could hold more, and more was measured to be slower (msize 9: +24 %)
     const int waves = cond ? e->waves_per_simd_cond : e->waves_per_simd;
     if (per_cu > 4 * waves) per_cu = 4 * waves;
+#ifdef PA_TUNING
     if (const char *env = std::getenv("PA_BLOCKS_PER_CU")) {
         const int v = std::atoi(env);
         if (v > 0) per_cu = v;
     }
+#endif
     const size_t cpb = 64 / lanes;
     size_t blocks = (n + cpb - 1) / cpb;
     const size_t resident = (size_t)per_cu * (size_t)ctx->num_cus;
@@ -722,6 +768,7 @@ static int run_local_ops(pa_context *ctx, pa_degree_info di, int quad_kind, int 
     double *d_oper = o.oper, *d_data = o.data, *d_stab = o.stab, *d_lc = o.lc;
     int32_t *d_info = o.info;
     if (!ctx) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->d_points) return PA_ERR_NO_MESH;
     if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
     PA_HIP(ctx, hipSetDevice(ctx->device));
@@ -731,14 +778,15 @@ static int run_local_ops(pa_context *ctx, pa_degree_info di, int quad_kind, int 
     if (st != PA_OK) return st;
     if (n == 0) return PA_OK;
     uint32_t ablate = 0;
-    if (const char *env = std::getenv("PA_ABLATE")) ablate = (uint32_t)std::strtoul(env, nullptr, 0);   // profiling only
+#ifdef PA_TUNING      // stage ablation produces garbage operators on purpose: never in the shipped library
+    if (const char *env = std::getenv("PA_ABLATE")) ablate = (uint32_t)std::strtoul(env, nullptr, 0);
+#endif
     const bool split = !o.cond && (d_data != nullptr || d_stab != nullptr);
     // Kernels that take the per-cell head from the pre-pass run in pieces of at most `piece` cells: pre-pass of a
     // piece into the context's record buffer, then the cooperative kernel over the same cells (same stream).
     size_t piece = n;
     if (e->launch_pre) {
-        size_t cap_bytes = (size_t)4 << 30;                               // 4 GiB of records: 7 M cells at k = 2, 3.9 M at k = 3
-        if (const char *env = std::getenv("PA_PRE_BYTES")) cap_bytes = (size_t)std::strtoull(env, nullptr, 0);
+        size_t cap_bytes = ctx->pre_cap_bytes;                            // default 4 GiB of records: 7 M cells at k = 2, 3.9 M at k = 3
         const size_t per_cell = (size_t)e->pre_doubles * sizeof(double);
         size_t max_cells = (cap_bytes / per_cell) & ~(size_t)4095;
         if (max_cells < 4096) max_cells = 4096;
@@ -844,6 +892,7 @@ int pa_condensed_recover_batch(pa_context *ctx, pa_degree_info di, int quad_kind
 static int launch_info(pa_context *ctx, pa_degree_info di, int quad_kind, int stab_kind, size_t n, bool cond, pa_launch_info *out)
 {
     if (!ctx || !out) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     const pa::KernelEntry *e = nullptr;
     int grid = 0;
     const int st = select_kernel(ctx, di, quad_kind, stab_kind, n, &e, &grid, cond);
@@ -927,6 +976,7 @@ int pa_cell_rhs_batch(pa_context *ctx, int degree, int dinc, int quad_kind, int 
                       size_t first, size_t n, double *d_rhs)
 {
     if (!ctx || !d_rhs || degree < 0 || dinc < 0) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->d_points) return PA_ERR_NO_MESH;
     if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
     if (fn < PA_FN_SAMPLED || fn > PA_FN_ONE || (fn == PA_FN_SAMPLED && !d_fvals)) return PA_ERR_INVALID_ARG;
@@ -944,6 +994,7 @@ int pa_project_function_batch(pa_context *ctx, pa_degree_info di, int quad_kind,
                               double *d_out, int32_t *d_info)
 {
     if (!ctx || !d_out || dinc < 0) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (di.cell_deg < 0 || di.cell_deg > 4 || di.face_deg < 0 || di.face_deg > 3) return PA_ERR_INVALID_DEGREE;
     if (!ctx->d_points) return PA_ERR_NO_MESH;
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
@@ -977,6 +1028,7 @@ int pa_energy_form_batch(pa_context *ctx, pa_degree_info di, size_t n, const dou
                          const double *d_v, double *d_out)
 {
     if (!ctx || !d_lc || !d_u || !d_out) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (di.cell_deg < 0 || di.cell_deg > 4 || di.face_deg < 0 || di.face_deg > 3) return PA_ERR_INVALID_DEGREE;
     if (n == 0) return PA_OK;
     const int msize = pa::P2(di.cell_deg) + 4 * (di.face_deg + 1);
@@ -991,6 +1043,7 @@ int pa_cell_quadrature_points(pa_context *ctx, int degree, int quad_kind, size_t
                               int32_t *nqp_out)
 {
     if (!ctx || degree < 0) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     int nqp = 0;
     const int st = rhs_quadrature(ctx, degree, quad_kind, &nqp);
     if (st != PA_OK) return st;
@@ -1031,6 +1084,7 @@ static int condense(pa_context *ctx, pa_degree_info di, size_t n, const double *
                     double *d_g, double *d_rec, int32_t *d_info, int packed)
 {
     if (!ctx || !d_lc) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     pa_sizes sz;
     const int st = pa_sizes_for(di, PA_QUAD_TENSOR, &sz);
     if (st != PA_OK && st != PA_ERR_QUADRATURE) return st;
@@ -1133,6 +1187,7 @@ int pa_condensed_partition_info(size_t Nx, size_t Ny, size_t row_begin, size_t r
 int pa_condensed_query(pa_context *ctx, pa_degree_info di, pa_condensed_info *out)
 {
     if (!ctx || !out || !cond_degree_ok(di)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     const int st = cond_prepare(ctx);
     if (st != PA_OK) return st;
     const uint64_t fbs = (uint64_t)di.face_deg + 1;
@@ -1153,6 +1208,7 @@ int pa_condensed_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first
                                 int32_t *d_rows, int32_t *d_cols, double *d_vals, int32_t *d_rhs_rows, double *d_rhs_vals)
 {
     if (!ctx || !d_cond || !d_rows || !d_cols || !d_vals || !d_rhs_rows || !d_rhs_vals) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!cond_degree_ok(di)) return PA_ERR_INVALID_DEGREE;
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
     if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
@@ -1166,6 +1222,7 @@ int pa_condensed_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first
 int pa_condensed_csr_pattern(pa_context *ctx, pa_degree_info di, int64_t *d_rowptr, int32_t *d_colind)
 {
     if (!ctx || !d_rowptr || !cond_degree_ok(di)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     const int st = cond_prepare(ctx);
     if (st != PA_OK) return st;
     if ((uint64_t)(di.face_deg + 1) * ctx->num_other_faces >= ((uint64_t)1 << 31)) return PA_ERR_INVALID_ARG;      // int32 column ids
@@ -1177,6 +1234,7 @@ int pa_condensed_csr_fill(pa_context *ctx, pa_degree_info di, const double *d_co
                           double *d_values, double *d_rhs)
 {
     if (!ctx || !d_cond || !d_values || !cond_degree_ok(di)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     const int st = cond_prepare(ctx);
     if (st != PA_OK) return st;
     if (ctx->structured && ctx->sm.row0 > 0 && !d_halo_below) {
@@ -1192,6 +1250,7 @@ int pa_condensed_csr_fill(pa_context *ctx, pa_degree_info di, const double *d_co
 int pa_condensed_halo_pack(pa_context *ctx, pa_degree_info di, const double *d_cond, const double *d_g, double *d_halo)
 {
     if (!ctx || !d_cond || !d_halo || !cond_degree_ok(di)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
     if (!ctx->structured || ctx->sm.row1 >= ctx->sm.Ny) return PA_OK;          // nothing above this slab
     PA_HIP(ctx, hipSetDevice(ctx->device));
@@ -1204,6 +1263,7 @@ int pa_condensed_take_faces(pa_context *ctx, pa_degree_info di, size_t first, si
                             double *d_uF)
 {
     if (!ctx || !d_solution || !d_uF) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!cond_degree_ok(di)) return PA_ERR_INVALID_DEGREE;
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
     if (first > ctx->ncells || n > ctx->ncells - first) return PA_ERR_INVALID_ARG;
@@ -1215,6 +1275,7 @@ int pa_condensed_take_faces(pa_context *ctx, pa_degree_info di, size_t first, si
 int pa_condensed_expand_solution(pa_context *ctx, pa_degree_info di, const double *d_uT, const double *d_xF, double *d_full)
 {
     if (!ctx || !d_uT || !d_full) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!cond_degree_ok(di)) return PA_ERR_INVALID_DEGREE;
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
     PA_HIP(ctx, hipSetDevice(ctx->device));
@@ -1242,6 +1303,7 @@ int pa_cut_preprocess_agglomeration(pa_context *ctx, size_t Nx, size_t Ny, doubl
 int pa_cut_agglo_query(pa_context *ctx, int8_t *agglo_set, int32_t *neighbors)
 {
     if (!ctx) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->cut) return PA_ERR_NO_MESH;
     if (agglo_set) {
         std::vector<int8_t> a;
@@ -1260,6 +1322,7 @@ static int cut_preprocess_impl(pa_context *ctx, size_t Nx, size_t Ny, double min
                                const pa_level_set *ls, int refsteps, bool displace)
 {
     if (!ctx || !ls || refsteps < 0 || refsteps > 10 || (ls->kind != 0 && ls->kind != 1)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     int st = pa_mesh_generate(ctx, Nx, Ny, min_x, max_x, min_y, max_y, 0, Ny);
     if (st != PA_OK) return st;
     pa::CutMeshHost *cm = new (std::nothrow) pa::CutMeshHost();
@@ -1321,6 +1384,7 @@ static int cut_preprocess_impl(pa_context *ctx, size_t Nx, size_t Ny, double min
 int pa_cut_query(pa_context *ctx, size_t *ncut, int8_t *cell_location, int32_t *cut_index)
 {
     if (!ctx) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->cut) return PA_ERR_NO_MESH;
     if (ncut) *ncut = ctx->cut->cut_cells.size();
     if (cell_location) std::memcpy(cell_location, ctx->cut->cell_loc.data(), ctx->cut->ncells());
@@ -1383,6 +1447,7 @@ int pa_cut_quadrature_points(pa_context *ctx, int face_deg, int where, int which
                              size_t *count)
 {
     if (!ctx || (where != PA_LOC_NEGATIVE && where != PA_LOC_POSITIVE) || which < 0 || which > 2) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->cut) return PA_ERR_NO_MESH;
     if (face_deg < 0) return PA_ERR_INVALID_DEGREE;
     if (face_deg > 2) return PA_ERR_QUADRATURE;
@@ -1407,6 +1472,7 @@ int pa_cut_quadrature_points(pa_context *ctx, int face_deg, int where, int which
 int pa_cut_query_tags(pa_context *ctx, int8_t *node_location, int8_t *face_location, double *points)
 {
     if (!ctx) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->cut) return PA_ERR_NO_MESH;
     const pa::CutMeshHost &cm = *ctx->cut;
     if (node_location) std::memcpy(node_location, cm.node_loc.data(), cm.npoints());
@@ -1442,7 +1508,9 @@ static int cut_local_ops(pa_context *ctx, int face_deg, const pa_level_set *ls, 
         // one wavefront per cut cell and a long serial chain per cell: as many blocks as the chip holds (2 per SIMD),
         // so that a few thousand cut cells take ONE cell's latency, not two or three
         size_t cap_blocks = (size_t)ctx->num_cus * 8;
+#ifdef PA_TUNING
         if (const char *env = std::getenv("PA_CUT_BLOCKS_PER_CU")) { const int v = std::atoi(env); if (v > 0) cap_blocks = (size_t)ctx->num_cus * v; }
+#endif
         const int grid = (int)(ncut < cap_blocks ? ncut : cap_blocks);
         // With pa_context_set_cut_overlap the kernel goes to the side stream, after everything enqueued on the
         // context's stream so far (the previous merge reads the buffers it writes); pa_cut_merge joins it.
@@ -1473,6 +1541,7 @@ int pa_cut_merge(pa_context *ctx, int face_deg, int where, const double *d_cut_l
                  double *d_rhs)
 {
     if (!ctx || face_deg < 0 || face_deg > 2 || (where != PA_LOC_NEGATIVE && where != PA_LOC_POSITIVE)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->cut) return PA_ERR_NO_MESH;
     const int cbs = pa::P2(face_deg + 1), ms = cbs + 4 * (face_deg + 1);
     const uint32_t nc = (uint32_t)ctx->cut->ncells();
@@ -1595,6 +1664,7 @@ int pa_cut_interface_uncut_batch(pa_context *ctx, int face_deg, const pa_interfa
 int pa_interface_assembler_query(pa_context *ctx, int face_deg, pa_interface_info *out)
 {
     if (!ctx || !out || face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->cut) return PA_ERR_NO_MESH;
     out->num_all_cells = ctx->if_num_all_cells;
     out->num_other_faces = ctx->if_num_other_faces;
@@ -1609,6 +1679,7 @@ int pa_interface_triplets_batch(pa_context *ctx, int face_deg, const double *d_l
                                 int32_t *d_rhs_rows, double *d_rhs_vals, int32_t *d_rhs_rows_cut, double *d_rhs_vals_cut)
 {
     if (!ctx || !d_lc || !d_rows || !d_cols || !d_vals || !d_rhs_rows || !d_rhs_vals) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_DEGREE;
     if (!ctx->cut || !ctx->d_cell_faces) return PA_ERR_NO_MESH;
     const size_t ncut = ctx->cut->cut_cells.size();
@@ -1636,6 +1707,7 @@ int pa_interface_triplets_batch(pa_context *ctx, int face_deg, const double *d_l
 int pa_interface_cell_offsets(pa_context *ctx, int face_deg, int64_t *d_offsets)
 {
     if (!ctx || !d_offsets || face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     if (!ctx->cut) return PA_ERR_NO_MESH;
     const pa::CutMeshHost &cm = *ctx->cut;
     const size_t nc = cm.ncells();

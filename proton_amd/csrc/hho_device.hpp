@@ -208,7 +208,10 @@ struct Cfg {
     // ---- LDS map (doubles, per cell).  Every vector that is read as a contiguous run starts at
     // an even offset and has an even stride, so the reads are 16-byte ds_read_b128.
     static constexpr int NRP = (NR + 1) & ~1;                 // padded row count of gr_lhs / Y
-    static constexpr int LD = (RBS + 1) & ~1;                 // stride of the (symmetric) stiffness matrix
+    // stride of the (symmetric) stiffness matrix / of the image of L: even (16-byte rows); for the 14 rows of k = 3 also
+    // LD / 2 odd, so that lanes reading DIFFERENT rows with 16-byte loads (row c-1 of L added to cell column c) do not
+    // share banks (LD = 16 put the 14 rows on two bank sets: 8-way conflicts, a quarter of the kernel's conflict cycles)
+    static constexpr int LD = (((RBS + 1) & ~1) % 4 == 0 && RBS > 10) ? ((RBS + 1) & ~1) + 2 : ((RBS + 1) & ~1);
     static constexpr int ZR = NRP + (HAS_STAB ? NF : 0);      // rows of Z = [Y; pad; U]
     static constexpr int ZS = ((ZR + 1) & ~1) % 4 == 2 ? ((ZR + 1) & ~1) : ((ZR + 1) & ~1) + 2;   // even, ZS/2 odd
     // region Q: quadrature-point tables and moments -- dead once the gr_rhs columns are in registers

@@ -364,12 +364,10 @@ class interface_assembler {
             }
         for (size_t i = 0; i < ms; ++i) {
             if (gidx[i] < 0) continue;
-            T moved = T(0);
             for (size_t j = 0; j < ms; ++j) {
                 if (gidx[j] >= 0) triplets.emplace_back((int32_t)gidx[i], (int32_t)gidx[j], lhs(i, j));
-                else moved += lhs(i, j) * dir[j];
+                else RHS[gidx[i]] -= lhs(i, j) * dir[j];      // term by term, the reference's order
             }
-            RHS[gidx[i]] -= moved;
         }
         for (size_t i = 0; i < cbs; ++i) RHS[gidx[i]] += rhs(i);
     }

@@ -38,6 +38,8 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <typeindex>
+#include <typeinfo>
 #include <utility>
 #include <vector>
 
@@ -71,31 +73,75 @@ inline const char *status_name(int st)
     }
 }
 
-// one context per process (device 0 unless PROTON_AMD_DEVICE is set), library-owned stream
+// One pa_context (one GPU, a library-owned stream) and everything the per-cell API caches for it.  The reference's
+// functions take no context argument, so the per-cell API runs on the CURRENT device of the calling thread: the default
+// instance (device 0 unless PROTON_AMD_DEVICE is set), or the one a device_scope has made current --
+//     proton_amd::device gpu1(1);
+//     { proton_amd::device_scope on(gpu1);  auto gr = make_hho_laplacian(msh, cl, hdi); ... }
+// Devices are independent: each owns its mesh copy and its batches (no state is shared between them).
 class device {
     pa_context *ctx_ = nullptr;
+    int index_ = 0;
+    std::map<std::type_index, std::shared_ptr<void>> slots_;      // per-device caches, by type (batch_cache<Mesh>)
+
+    static int default_index()
+    {
+        if (const char *e = std::getenv("PROTON_AMD_DEVICE")) return std::atoi(e);
+        return 0;
+    }
+    static device *&current_slot()
+    {
+        static thread_local device *cur = nullptr;
+        return cur;
+    }
+    friend class device_scope;
 
   public:
-    device()
+    device() : device(default_index()) {}
+    explicit device(int dev) : index_(dev)
     {
-        int dev = 0;
-        if (const char *e = std::getenv("PROTON_AMD_DEVICE")) dev = std::atoi(e);
         const int st = pa_context_create(dev, nullptr, 1, &ctx_);
         if (st != PA_OK) throw error(st, std::string("pa_context_create: ") + status_name(st) + " (no GPU? there is no CPU fallback)");
     }
-    ~device() { if (ctx_) pa_context_destroy(ctx_); }
+    ~device()
+    {
+        slots_.clear();
+        if (ctx_) pa_context_destroy(ctx_);
+    }
     device(const device &) = delete;
     device &operator=(const device &) = delete;
     pa_context *ctx() const { return ctx_; }
+    int index() const { return index_; }
     void check(int st, const char *where) const
     {
         if (st != PA_OK) throw error(st, std::string(where) + ": " + status_name(st) + " " + pa_last_error(ctx_));
     }
+    // the cache object of type T this device owns (created on first use)
+    template <typename T>
+    T &slot()
+    {
+        auto &p = slots_[std::type_index(typeid(T))];
+        if (!p) p = std::make_shared<T>();
+        return *static_cast<T *>(p.get());
+    }
+    // the device the per-cell API of the calling thread runs on
     static device &instance()
     {
+        if (device *c = current_slot()) return *c;
         static device d;
         return d;
     }
+};
+
+// makes `d` the current device of the calling thread for the scope's lifetime
+class device_scope {
+    device *prev_;
+
+  public:
+    explicit device_scope(device &d) : prev_(device::current_slot()) { device::current_slot() = &d; }
+    ~device_scope() { device::current_slot() = prev_; }
+    device_scope(const device_scope &) = delete;
+    device_scope &operator=(const device_scope &) = delete;
 };
 
 // RAII device buffer
@@ -103,6 +149,7 @@ template <typename T>
 class device_buffer {
     T *p_ = nullptr;
     size_t n_ = 0;
+    device *dev_ = nullptr;       // the device it was allocated on (freed there, whatever is current then)
 
   public:
     device_buffer() = default;
@@ -110,25 +157,26 @@ class device_buffer {
     ~device_buffer() { release(); }
     device_buffer(const device_buffer &) = delete;
     device_buffer &operator=(const device_buffer &) = delete;
-    device_buffer(device_buffer &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    device_buffer(device_buffer &&o) noexcept : p_(o.p_), n_(o.n_), dev_(o.dev_) { o.p_ = nullptr; o.n_ = 0; }
     void release()
     {
-        if (p_) pa_free(device::instance().ctx(), p_);
+        if (p_) pa_free(dev_->ctx(), p_);
         p_ = nullptr; n_ = 0;
     }
     void resize(size_t n)
     {
         release();
+        dev_ = &device::instance();
         void *q = nullptr;
-        device::instance().check(pa_malloc(device::instance().ctx(), n * sizeof(T), &q), "pa_malloc");
+        dev_->check(pa_malloc(dev_->ctx(), n * sizeof(T), &q), "pa_malloc");
         p_ = static_cast<T *>(q); n_ = n;
     }
     T *get() const { return p_; }
     size_t size() const { return n_; }
-    void upload(const T *src, size_t n) { device::instance().check(pa_memcpy_h2d(device::instance().ctx(), p_, src, n * sizeof(T)), "pa_memcpy_h2d"); }
+    void upload(const T *src, size_t n) { dev_->check(pa_memcpy_h2d(dev_->ctx(), p_, src, n * sizeof(T)), "pa_memcpy_h2d"); }
     void download(T *dst, size_t n, size_t offset = 0) const
     {
-        device::instance().check(pa_memcpy_d2h(device::instance().ctx(), dst, p_ + offset, n * sizeof(T)), "pa_memcpy_d2h");
+        dev_->check(pa_memcpy_d2h(dev_->ctx(), dst, p_ + offset, n * sizeof(T)), "pa_memcpy_d2h");
     }
 };
 
@@ -442,19 +490,24 @@ class mesh_on_device {
   public:
     const Mesh *msh = nullptr;
     size_t npoints = 0, ncells = 0;
-    double probe = 0.0;      // cheap change detector: sum of a few coordinates
+    uint64_t probe = 0;      // change detector: hash of EVERY point coordinate (FNV-1a over the bit patterns)
 
-    static double make_probe(const Mesh &m)
+    static uint64_t make_probe(const Mesh &m)
     {
-        double s = 0.0;
-        const size_t n = m.points.size(), step = n / 16 + 1;
-        for (size_t i = 0; i < n; i += step) s += m.points[i].x() * 3.0 + m.points[i].y();
-        return s;
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < m.points.size(); ++i) {
+            const double xy[2] = {m.points[i].x(), m.points[i].y()};
+            uint64_t b[2];
+            std::memcpy(b, xy, sizeof(b));
+            h = (h ^ b[0]) * 1099511628211ull;
+            h = (h ^ b[1]) * 1099511628211ull;
+        }
+        return h;
     }
-    bool matches(const Mesh &m) const
-    {
-        return msh == &m && npoints == m.points.size() && ncells == m.cells.size() && probe == make_probe(m);
-    }
+    // same object and sizes: the cheap test of every per-cell call
+    bool same_object(const Mesh &m) const { return msh == &m && npoints == m.points.size() && ncells == m.cells.size(); }
+    // ... and the same coordinates, every one of them (an O(points) pass)
+    bool matches(const Mesh &m) const { return same_object(m) && probe == make_probe(m); }
     // msh.points, cell.ptids and msh.faces as the reference holds them
     void upload(const Mesh &m)
     {
@@ -492,32 +545,63 @@ class batch_cache {
     mesh_on_device<Mesh> dev_mesh_;
     std::map<std::tuple<int, int, int, int>, std::shared_ptr<local_batch>> batches_;
     std::map<std::tuple<int, int, int>, std::vector<double>> qpoints_;      // (degree, quad) -> n x nq x 3
+    size_t last_pos_ = 0;
+    std::map<int, std::vector<double>> face_qpoints_;                       // Gauss points per face -> nfaces x nfq x 3
+    std::map<int, std::shared_ptr<device_buffer<double>>> face_samples_;    // ... -> device array nfaces x nfq of samples
 
   public:
-    static batch_cache &instance()
+    // the cache of the calling thread's current device (device::instance(), device_scope)
+    static batch_cache &instance() { return device::instance().template slot<batch_cache>(); }
+    // The cached mesh copy and batches serve `m` only while m is the same object with the same coordinates.  The
+    // coordinates are re-hashed in full whenever a per-cell call does not continue a forward sweep over the cells
+    // (pos = the cell's offset; the reference's drivers edit a mesh between their loops over the cells, not inside
+    // one), and by every call that is not tied to a cell.  Editing a mesh in the middle of a sweep needs
+    // proton_amd::invalidate(msh).
+    void ensure_mesh(const Mesh &m, size_t pos = 0)
     {
-        static batch_cache c;
-        return c;
-    }
-    void ensure_mesh(const Mesh &m)
-    {
-        if (!dev_mesh_.matches(m)) {
-            batches_.clear(); qpoints_.clear();
+        const bool sweep_continues = pos > last_pos_;
+        last_pos_ = pos;
+        if (sweep_continues ? !dev_mesh_.same_object(m) : !dev_mesh_.matches(m)) {
+            batches_.clear(); qpoints_.clear(); face_qpoints_.clear(); face_samples_.clear();
             dev_mesh_.upload(m);
         }
     }
-    void invalidate() { dev_mesh_ = mesh_on_device<Mesh>(); batches_.clear(); qpoints_.clear(); }
+    // points of integrate(msh, fc, 2 (nfq - 1)) for every face (x, y, w), and a device array for per-face samples
+    const std::vector<double> &face_qpoints(const Mesh &m, int nfq, size_t pos = 0)
+    {
+        ensure_mesh(m, pos);
+        auto it = face_qpoints_.find(nfq);
+        if (it != face_qpoints_.end()) return it->second;
+        auto &dev = device::instance();
+        const size_t nf = m.faces.size();
+        device_buffer<double> d(nf * nfq * 3);
+        dev.check(pa_face_quadrature_points(dev.ctx(), nfq - 1, d.get()), "pa_face_quadrature_points");
+        std::vector<double> h(nf * nfq * 3);
+        d.download(h.data(), h.size());
+        return face_qpoints_[nfq] = std::move(h);
+    }
+    device_buffer<double> &face_samples(const Mesh &m, int nfq)
+    {
+        auto &p = face_samples_[nfq];
+        if (!p || p->size() != m.faces.size() * nfq) {
+            p = std::make_shared<device_buffer<double>>(m.faces.size() * nfq);
+            auto &dev = device::instance();
+            dev.check(pa_memset(dev.ctx(), p->get(), 0, p->size() * sizeof(double)), "pa_memset");
+        }
+        return *p;
+    }
+    void invalidate() { dev_mesh_ = mesh_on_device<Mesh>(); batches_.clear(); qpoints_.clear(); face_qpoints_.clear(); face_samples_.clear(); }
     // the context already holds this mesh (pa_cut_preprocess built it): no upload
     void adopt(const Mesh &m)
     {
-        batches_.clear(); qpoints_.clear();
+        batches_.clear(); qpoints_.clear(); face_qpoints_.clear(); face_samples_.clear();
         dev_mesh_.msh = &m; dev_mesh_.npoints = m.points.size(); dev_mesh_.ncells = m.cells.size();
         dev_mesh_.probe = mesh_on_device<Mesh>::make_probe(m);
     }
 
-    std::shared_ptr<local_batch> get(const Mesh &m, const hho_degree_info &hdi, int quad, int stab)
+    std::shared_ptr<local_batch> get(const Mesh &m, const hho_degree_info &hdi, int quad, int stab, size_t pos = 0)
     {
-        ensure_mesh(m);
+        ensure_mesh(m, pos);
         const auto key = std::make_tuple((int)hdi.cell_degree(), (int)hdi.face_degree(), quad, stab);
         auto it = batches_.find(key);
         if (it != batches_.end()) return it->second;
@@ -539,9 +623,9 @@ class batch_cache {
     }
 
     // quadrature points of integrate(msh, cl, degree) for every cell (x, y, w)
-    const std::vector<double> &cell_qpoints(const Mesh &m, int degree, int quad, int &nq)
+    const std::vector<double> &cell_qpoints(const Mesh &m, int degree, int quad, int &nq, size_t pos = 0)
     {
-        ensure_mesh(m);
+        ensure_mesh(m, pos);
         auto &dev = device::instance();
         int32_t nqp = 0;
         dev.check(pa_cell_quadrature_points(dev.ctx(), degree, quad, 0, 0, nullptr, &nqp), "pa_cell_quadrature_points");
@@ -580,8 +664,8 @@ std::pair<proton_amd::dense_matrix<typename Mesh::coordinate_type>, proton_amd::
 make_hho_laplacian(const Mesh &msh, const typename Mesh::cell_type &cl, const hho_degree_info &di)
 {
     using T = typename Mesh::coordinate_type;
-    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, Mesh::pa_quadrature, PA_STAB_FANCY);
     const size_t c = offset(msh, cl);
+    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, Mesh::pa_quadrature, PA_STAB_FANCY, c);
     return std::make_pair(proton_amd::copy_cell<T>(b->oper, c, b->sz.oper_rows, b->sz.msize),
                           proton_amd::copy_cell<T>(b->data, c, b->sz.msize, b->sz.msize));
 }
@@ -592,21 +676,30 @@ proton_amd::dense_matrix<typename Mesh::coordinate_type>
 make_hho_naive_stabilization(const Mesh &msh, const typename Mesh::cell_type &cl, const hho_degree_info &di)
 {
     using T = typename Mesh::coordinate_type;
-    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, Mesh::pa_quadrature, PA_STAB_NAIVE);
-    return proton_amd::copy_cell<T>(b->stab, offset(msh, cl), b->sz.msize, b->sz.msize);
+    const size_t c = offset(msh, cl);
+    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, Mesh::pa_quadrature, PA_STAB_NAIVE, c);
+    return proton_amd::copy_cell<T>(b->stab, c, b->sz.msize, b->sz.msize);
 }
 
-// hho.hpp:155-159.  `reconstruction` is make_hho_laplacian(...).first of the same cell; the batch
-// recomputes it on the device, so the argument only documents the dependency.
+// hho.hpp:155-159.  The reference builds the stabilization from the `reconstruction` it is handed (hho.hpp:184-190,
+// 222-226).  The batch computes it from the reconstruction operator of the same cell, so the argument must BE that
+// operator -- make_hho_laplacian(msh, cl, di).first, what every driver of the reference passes -- and anything else is
+// refused rather than silently answered with the stabilization of a different matrix.
 template <typename Mesh>
 proton_amd::dense_matrix<typename Mesh::coordinate_type>
 make_hho_fancy_stabilization(const Mesh &msh, const typename Mesh::cell_type &cl,
-                             const proton_amd::dense_matrix<typename Mesh::coordinate_type> & /*reconstruction*/,
+                             const proton_amd::dense_matrix<typename Mesh::coordinate_type> &reconstruction,
                              const hho_degree_info &di)
 {
     using T = typename Mesh::coordinate_type;
-    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, Mesh::pa_quadrature, PA_STAB_FANCY);
-    return proton_amd::copy_cell<T>(b->stab, offset(msh, cl), b->sz.msize, b->sz.msize);
+    const size_t c = offset(msh, cl);
+    auto b = proton_amd::batch_cache<Mesh>::instance().get(msh, di, Mesh::pa_quadrature, PA_STAB_FANCY, c);
+    const size_t om = (size_t)b->sz.oper_rows * b->sz.msize;
+    if (reconstruction.rows() != (size_t)b->sz.oper_rows || reconstruction.cols() != (size_t)b->sz.msize ||
+        std::memcmp(reconstruction.data(), b->oper.data() + c * om, om * sizeof(double)) != 0)
+        throw std::invalid_argument("make_hho_fancy_stabilization: `reconstruction` is not make_hho_laplacian(msh, cl, di).first of this "
+                                    "cell; the device batch computes the stabilization of the cell's own reconstruction operator only");
+    return proton_amd::copy_cell<T>(b->stab, c, b->sz.msize, b->sz.msize);
 }
 
 // utils.hpp:153-156.  The functor runs on the host at the quadrature points of
@@ -619,8 +712,8 @@ make_rhs(const Mesh &msh, const typename Mesh::cell_type &cl, size_t degree, con
     auto &cache = proton_amd::batch_cache<Mesh>::instance();
     auto &dev = proton_amd::device::instance();
     int nq = 0;
-    const auto &xyw = cache.cell_qpoints(msh, (int)(2 * (degree + di)), Mesh::pa_quadrature, nq);
     const size_t c = offset(msh, cl);
+    const auto &xyw = cache.cell_qpoints(msh, (int)(2 * (degree + di)), Mesh::pa_quadrature, nq, c);
     std::vector<double> fv(nq);
     for (int q = 0; q < nq; ++q) fv[q] = f(typename Mesh::point_type(xyw[(c * nq + q) * 3], xyw[(c * nq + q) * 3 + 1]));
     const size_t cbs = (degree + 2) * (degree + 1) / 2;
@@ -633,42 +726,68 @@ make_rhs(const Mesh &msh, const typename Mesh::cell_type &cl, size_t degree, con
     return ret;
 }
 
-// utils.hpp:199-227.  The functor is sampled on the host at the points of
-// integrate(msh, cl, 2*(celdeg+di)) and integrate(msh, fc, 2*(facdeg+di)); the mass matrices,
-// right-hand sides and LLT solves run on the device for ALL cells at the first call with a given
-// functor (one batch per functor object), later calls copy one cell out.
+// utils.hpp:199-227.  The functor is sampled on the host at the points of integrate(msh, cl, 2*(celdeg+di)) and, for
+// the cell's four faces, integrate(msh, fc, 2*(facdeg+di)); the mass matrices, right-hand sides and LLT solves of THIS
+// cell run on the device.  Nothing of the result is cached: the functor is evaluated afresh at every call (a cache
+// keyed on the functor's address would hand a re-created temporary the previous functor's projection).  Drivers
+// that project one function on every cell use project_function_all below (one device batch).
 template <typename Mesh, typename Function>
 proton_amd::dense_matrix<typename Mesh::coordinate_type>
 project_function(const Mesh &msh, const typename Mesh::cell_type &cl, hho_degree_info hdi, const Function &f, size_t di = 0)
 {
     using T = typename Mesh::coordinate_type;
-    struct cached { const void *fn = nullptr; const Mesh *msh = nullptr; size_t cd = 0, fd = 0, di = 0; std::vector<double> all; };
-    static cached cache;
+    auto &dev = proton_amd::device::instance();
+    auto &bc = proton_amd::batch_cache<Mesh>::instance();
+    const size_t cd = hdi.cell_degree(), fd = hdi.face_degree();
+    const size_t cbs = (cd + 2) * (cd + 1) / 2, fbs = fd + 1, ms = cbs + 4 * fbs, c = offset(msh, cl);
+    int nq = 0;
+    const auto &xyw = bc.cell_qpoints(msh, (int)(2 * (cd + di)), Mesh::pa_quadrature, nq, c);
+    std::vector<double> cv(nq);
+    for (int q = 0; q < nq; ++q) cv[q] = f(typename Mesh::point_type(xyw[(c * nq + q) * 3], xyw[(c * nq + q) * 3 + 1]));
+    const int nfq = (int)(fd + di + 1);
+    const auto &fx = bc.face_qpoints(msh, nfq, c);
+    auto &d_fv = bc.face_samples(msh, nfq);
+    const auto fcs = faces(msh, cl);
+    for (size_t lf = 0; lf < 4; ++lf) {
+        const size_t fo = offset(msh, fcs[lf]);
+        std::vector<double> fv(nfq);
+        for (int q = 0; q < nfq; ++q) fv[q] = f(typename Mesh::point_type(fx[(fo * nfq + q) * 3], fx[(fo * nfq + q) * 3 + 1]));
+        dev.check(pa_memcpy_h2d(dev.ctx(), d_fv.get() + fo * nfq, fv.data(), nfq * sizeof(double)), "pa_memcpy_h2d");
+    }
+    proton_amd::device_buffer<double> d_cv(nq), d_out(ms);
+    d_cv.upload(cv.data(), nq);
+    dev.check(pa_project_function_batch(dev.ctx(), hdi.c_abi(), Mesh::pa_quadrature, (int)di, PA_FN_SAMPLED, d_cv.get(), d_fv.get(), c, 1,
+                                        d_out.get(), nullptr), "pa_project_function_batch");
+    proton_amd::dense_matrix<T> ret(ms, 1);
+    d_out.download(ret.data(), ms);
+    return ret;
+}
+
+// The same for every cell in one device batch: ncells x msize coefficients, cell-major (cell c at [c * msize, ...)).
+template <typename Mesh, typename Function>
+std::vector<typename Mesh::coordinate_type>
+project_function_all(const Mesh &msh, hho_degree_info hdi, const Function &f, size_t di = 0)
+{
+    auto &dev = proton_amd::device::instance();
+    auto &bc = proton_amd::batch_cache<Mesh>::instance();
     const size_t cd = hdi.cell_degree(), fd = hdi.face_degree();
     const size_t cbs = (cd + 2) * (cd + 1) / 2, fbs = fd + 1, ms = cbs + 4 * fbs, n = msh.cells.size(), nf = msh.faces.size();
-    if (cache.fn != (const void *)&f || cache.msh != &msh || cache.cd != cd || cache.fd != fd || cache.di != di || cache.all.size() != n * ms) {
-        auto &dev = proton_amd::device::instance();
-        auto &bc = proton_amd::batch_cache<Mesh>::instance();
-        int nq = 0;
-        const auto &xyw = bc.cell_qpoints(msh, (int)(2 * (cd + di)), Mesh::pa_quadrature, nq);
-        std::vector<double> cv(n * nq);
-        for (size_t k = 0; k < n * (size_t)nq; ++k) cv[k] = f(typename Mesh::point_type(xyw[3 * k], xyw[3 * k + 1]));
-        const size_t nfq = fd + di + 1;
-        proton_amd::device_buffer<double> d_fx(nf * nfq * 3);
-        dev.check(pa_face_quadrature_points(dev.ctx(), (int)(fd + di), d_fx.get()), "pa_face_quadrature_points");
-        std::vector<double> fx(nf * nfq * 3), fv(nf * nfq);
-        d_fx.download(fx.data(), fx.size());
-        for (size_t k = 0; k < nf * nfq; ++k) fv[k] = f(typename Mesh::point_type(fx[3 * k], fx[3 * k + 1]));
-        proton_amd::device_buffer<double> d_cv(cv.size()), d_fv(fv.size()), d_out(n * ms);
-        d_cv.upload(cv.data(), cv.size());
-        d_fv.upload(fv.data(), fv.size());
-        dev.check(pa_project_function_batch(dev.ctx(), hdi.c_abi(), Mesh::pa_quadrature, (int)di, PA_FN_SAMPLED, d_cv.get(), d_fv.get(), 0, n,
-                                            d_out.get(), nullptr), "pa_project_function_batch");
-        cache.all.resize(n * ms);
-        d_out.download(cache.all.data(), cache.all.size());
-        cache.fn = (const void *)&f; cache.msh = &msh; cache.cd = cd; cache.fd = fd; cache.di = di;
-    }
-    return proton_amd::copy_cell<T>(cache.all, offset(msh, cl), ms, 1);
+    int nq = 0;
+    const auto &xyw = bc.cell_qpoints(msh, (int)(2 * (cd + di)), Mesh::pa_quadrature, nq);
+    std::vector<double> cv(n * nq);
+    for (size_t k = 0; k < n * (size_t)nq; ++k) cv[k] = f(typename Mesh::point_type(xyw[3 * k], xyw[3 * k + 1]));
+    const int nfq = (int)(fd + di + 1);
+    const auto &fx = bc.face_qpoints(msh, nfq);
+    std::vector<double> fv(nf * nfq);
+    for (size_t k = 0; k < nf * (size_t)nfq; ++k) fv[k] = f(typename Mesh::point_type(fx[3 * k], fx[3 * k + 1]));
+    proton_amd::device_buffer<double> d_cv(cv.size()), d_fv(fv.size()), d_out(n * ms);
+    d_cv.upload(cv.data(), cv.size());
+    d_fv.upload(fv.data(), fv.size());
+    dev.check(pa_project_function_batch(dev.ctx(), hdi.c_abi(), Mesh::pa_quadrature, (int)di, PA_FN_SAMPLED, d_cv.get(), d_fv.get(), 0, n,
+                                        d_out.get(), nullptr), "pa_project_function_batch");
+    std::vector<typename Mesh::coordinate_type> all(n * ms);
+    d_out.download(all.data(), all.size());
+    return all;
 }
 
 namespace proton_amd {
@@ -679,8 +798,8 @@ namespace proton_amd {
 template <typename Mesh>
 class face_numbering {
     using T = typename Mesh::coordinate_type;
-    std::vector<double> face_xyw_, g_;
-    const void *g_owner_ = nullptr;
+    std::vector<double> face_xyw_, g_, samples_;
+    std::vector<size_t> probe_idx_;      // sample positions on Dirichlet faces at which a cached result is re-checked
 
   public:
     std::vector<int64_t> compress;
@@ -699,7 +818,16 @@ class face_numbering {
     template <typename Function>
     const std::vector<double> &dirichlet_data(const Mesh &msh, const Function &bf)
     {
-        if (g_owner_ == (const void *)&bf && !g_.empty()) return g_;
+        // The data of one boundary function serve every cell of an assembly loop.  They are NOT tied to the functor's
+        // address (a re-created temporary may live where the previous functor did): a cached result is reused only
+        // while the functor still takes the cached values at a handful of boundary quadrature points spread over the
+        // Dirichlet faces; two functors that agree at all of them and differ elsewhere need a fresh assembler.
+        if (!g_.empty()) {
+            bool same = true;
+            for (size_t k : probe_idx_)
+                if (bf(typename Mesh::point_type(face_xyw_[3 * k], face_xyw_[3 * k + 1])) != samples_[k]) { same = false; break; }
+            if (same) return g_;
+        }
         auto &dev = device::instance();
         batch_cache<Mesh>::instance().ensure_mesh(msh);
         const size_t nf = msh.faces.size(), nq = fbs;       // integrate(msh, fc, 2*facdeg): facdeg+1 Gauss points
@@ -709,14 +837,21 @@ class face_numbering {
             face_xyw_.resize(nf * nq * 3);
             d.download(face_xyw_.data(), face_xyw_.size());
         }
-        std::vector<double> samples(nf * nq);
+        std::vector<double> &samples = samples_;
+        samples.resize(nf * nq);
         for (size_t k = 0; k < nf * nq; ++k) samples[k] = bf(typename Mesh::point_type(face_xyw_[3 * k], face_xyw_[3 * k + 1]));
+        if (probe_idx_.empty()) {
+            std::vector<size_t> on_boundary;
+            for (size_t f = 0; f < nf; ++f)
+                if (compress[f] < 0) for (size_t q = 0; q < nq; ++q) on_boundary.push_back(f * nq + q);
+            const size_t want = std::min<size_t>(8, on_boundary.size());
+            for (size_t i = 0; i < want; ++i) probe_idx_.push_back(on_boundary[i * on_boundary.size() / want]);
+        }
         device_buffer<double> d_f(nf * nq), d_g(nf * fbs);
         d_f.upload(samples.data(), samples.size());
         dev.check(pa_dirichlet_data_batch(dev.ctx(), (int)face_degree, PA_FN_SAMPLED, d_f.get(), d_g.get()), "pa_dirichlet_data_batch");
         g_.resize(nf * fbs);
         d_g.download(g_.data(), g_.size());
-        g_owner_ = (const void *)&bf;
         return g_;
     }
 };
@@ -787,12 +922,10 @@ class assembler {
         if (lhs.rows() != ms || lhs.cols() != ms) throw std::invalid_argument("assembler::assemble: local matrix size");
         for (size_t i = 0; i < ms; ++i) {
             if (gidx[i] < 0) continue;
-            T moved = T(0);
             for (size_t j = 0; j < ms; ++j) {
                 if (gidx[j] >= 0) triplets.emplace_back((int32_t)gidx[i], (int32_t)gidx[j], lhs(i, j));
-                else moved += lhs(i, j) * dir[j];
+                else RHS[gidx[i]] -= lhs(i, j) * dir[j];             // term by term, the reference's order (hho.hpp:401)
             }
-            RHS[gidx[i]] -= moved;
         }
         for (size_t i = 0; i < numbering.cbs; ++i) RHS[gidx[i]] += rhs(i);
     }
@@ -968,12 +1101,10 @@ class obstacle_assembler {
         if (lhs.rows() != ms || lhs.cols() != ms) throw std::invalid_argument("obstacle_assembler::assemble: local matrix size");
         for (size_t i = 0; i < ms; ++i) {
             if (row[i] < 0) continue;
-            T moved = T(0);
             for (size_t j = 0; j < ms; ++j) {
                 if (col[j] >= 0) triplets.emplace_back((int32_t)row[i], (int32_t)col[j], lhs(i, j));
-                else moved += lhs(i, j) * known[j];
+                else RHS[row[i]] -= lhs(i, j) * known[j];      // term by term, the reference's order
             }
-            RHS[row[i]] -= moved;
         }
         for (size_t i = 0; i < cbs; ++i) RHS[c + i] += rhs(i);                           // :686
         if (active)                                                                       // :688-693

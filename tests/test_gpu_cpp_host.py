@@ -117,3 +117,13 @@ def test_batched_api_same_as_per_cell(driver):
     # config 1 of BASELINE.json: 32x32 k=1 (plumbing), batched
     e3, r3, out = run(driver, 1, 16, 2, "batched")
     assert r3[-1] > 2.7 and "N 32" in out
+
+
+def test_boundary_fidelity_driver():
+    """tests/cpp/boundary_driver.cpp: temporaries in project_function, a mesh edited in place between sweeps, the
+    `reconstruction` argument of make_hho_fancy_stabilization, two devices in one process."""
+    exe = _compile("boundary_driver")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    for n in (1, 2, 3, 4):
+        assert "check %d ok" % n in r.stdout, r.stdout

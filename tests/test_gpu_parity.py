@@ -165,10 +165,10 @@ def test_batch_matches_oracle(asm, oracle, cd, fd, kind, stabname):
 
 @pytest.mark.parametrize("cd,fd,kind,stabname", [(3, 2, "tensor", "fancy"), (2, 1, "fan", "naive"), (4, 3, "tensor", "fancy"),
                                                  (0, 1, "tensor", "fancy"), (2, 2, "tensor", "fancy")])      # the last two: dense fancy form
-def test_pre_pass_in_pieces(asm, oracle, cd, fd, kind, stabname, monkeypatch):
+def test_pre_pass_in_pieces(asm, oracle, cd, fd, kind, stabname):
     """The split path (one-thread-per-cell pre-pass + cooperative kernel, hho_pre.hpp) runs in pieces when the record
-    buffer is capped (PA_PRE_BYTES; 1 GiB by default, i.e. pieces from 1-2 M cells on): same results piece by piece,
-    bit for bit, as in one pass, and both match the oracle."""
+    buffer is capped (pa_context_set_record_cap; 4 GiB by default, i.e. pieces from 4-7 M cells on): same results piece
+    by piece, bit for bit, as in one pass, and both match the oracle; pa_context_trim gives the buffer back."""
     import torch
     import proton_amd as pa
     from proton_amd.batch import to_rowcol
@@ -180,10 +180,11 @@ def test_pre_pass_in_pieces(asm, oracle, cd, fd, kind, stabname, monkeypatch):
     whole = asm.local_ops(cd, fd, quad, stab, want=("oper", "lc", "info"))
     asm.synchronize()
     whole = {k: v.clone() for k, v in whole.items()}
-    monkeypatch.setenv("PA_PRE_BYTES", "1")  # clamps to the minimum piece (4096 cells)
+    asm.ctx.trim()
+    asm.ctx.set_record_cap(1 << 20)          # clamps to the minimum piece (4096 cells)
     pieces = asm.local_ops(cd, fd, quad, stab, want=("oper", "lc", "info"))
     asm.synchronize()
-    monkeypatch.delenv("PA_PRE_BYTES")
+    asm.ctx.set_record_cap(4 << 30)
     for k in ("oper", "lc", "info"):
         assert torch.equal(whole[k], pieces[k]), k
     di = oracle.degrees(cd, fd)

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Reduce rocprofv3 counter_collection CSVs (separate --pmc passes) to per-kernel, per-dispatch means for every pa::
 kernel; FETCH/WRITE in bytes with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half the bytes of a
-wide streaming read: doubled; both counters are in KiB).   profile_reduce.py <dir> <workload> <mode> [bench.json]"""
-import collections, csv, glob, json, sys
+wide streaming read: doubled; both counters are in KiB).  A step may launch a kernel several times (2048^2 k=3: two
+pieces under the 4 GiB record cap): per-step figures = the sum over a pass's dispatches / the number of steps of that
+pass (PA_PROFILE_STEPS, default 4 = --steps 3 --warmup 1).   profile_reduce.py <dir> <workload> <mode> [bench.json]"""
+import collections, csv, glob, json, os, sys
 d, workload, mode = sys.argv[1], sys.argv[2], sys.argv[3]
+STEPS = int(os.environ.get("PA_PROFILE_STEPS", "4"))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True):
     per = collections.defaultdict(float)
@@ -17,8 +20,10 @@ for f in glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True):
 out = {"workload": workload, "mode": mode, "kernels": {}}
 dominant = 0.0
 for k, cs in sorted(acc.items()):
-    m = {c: sum(v) / len(v) for c, v in cs.items()}
-    rec = {"dispatches": max(len(v) for v in cs.values()), "per_dispatch_means": m}
+    ndisp = max(len(v) for v in cs.values())
+    per_step = ndisp / STEPS if ("hho_local_ops_kernel" in k or "hho_cell_pre_kernel" in k or "cond_fill" in k or "cell_rhs" in k) and ndisp >= STEPS else 1.0
+    m = {c: sum(v) / len(v) * per_step for c, v in cs.items()}
+    rec = {"dispatches_per_step": per_step, "per_step_sums" if per_step != 1.0 else "per_dispatch_means": m}
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         rec["FETCH_SIZE_bytes"] = m["FETCH_SIZE"] * 1024
         rec["WRITE_SIZE_bytes"] = m["WRITE_SIZE"] * 1024
