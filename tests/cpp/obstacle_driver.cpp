@@ -2,9 +2,10 @@
 // primal-dual active set iteration over make_hho_laplacian / make_hho_fancy_stabilization /
 // make_rhs(di = 1) / obstacle_assembler, expand_solution, and the energy error against
 // project_function(sol_fun, di = 1).  The reference solves with Eigen::SparseLU (obstacle.cpp:170-175,
-// outside the hot path); here a dense LU with partial pivoting stands in, which bounds N to ~24.
+// outside the hot path); here the block-triangular structure of the system is used (block_solve below): the
+// reference's own conjugate gradient on the device for its SPD block, so that config 4 (512 x 512, k = 1) runs end to end.
 // Compiled against proton_amd/host/hho.hpp only: no Eigen, no HIP headers.
-//   usage: obstacle_driver <degree> <N> [batched]
+//   usage: obstacle_driver <degree> <N> [batched|percell] [max outer iterations, default 50 = obstacle.cpp:119]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,34 +15,50 @@
 using RealType = double;
 using mesh_type = quad_mesh<RealType>;
 
-// x = A^-1 b, A given as CSR; dense Gaussian elimination with row pivoting
-static std::vector<RealType> dense_solve(const proton_amd::sparse_matrix<RealType> &A, const std::vector<RealType> &b)
+// x = A^-1 b for the system of obstacle_assembler (hho.hpp:471-751).  The reference hands it to Eigen::SparseLU
+// (obstacle.cpp:170-175, outside the hot path); Eigen is not available here, and no sparse LU ships with the image.  The
+// system is block triangular by construction: the multiplier of an active cell appears in that cell's row only, with
+// coefficient 1 (hho.hpp:688-693), so with the active rows set aside what remains -- rows of the inactive cells and of
+// the faces, columns of the same unknowns -- is the symmetric positive definite HHO matrix with the active cells'
+// values fixed.  That block is solved with the reference's own Jacobi-preconditioned conjugate gradient on the device
+// (conjugated_gradient, solver_cg.hpp:63-144 -> pa_conjugated_gradient), the multipliers follow from their rows.
+static std::vector<RealType> block_solve(const proton_amd::sparse_matrix<RealType> &A, const std::vector<RealType> &b, size_t nk)
 {
     const size_t n = A.rows();
-    std::vector<RealType> M(n * n, 0.0), x(b);
-    for (size_t i = 0; i < n; ++i)
-        for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) M[i * n + A.colind[k]] = A.values[k];
-    for (size_t p = 0; p < n; ++p) {
-        size_t best = p;
-        for (size_t i = p + 1; i < n; ++i)
-            if (std::fabs(M[i * n + p]) > std::fabs(M[best * n + p])) best = i;
-        if (best != p) {
-            for (size_t j = 0; j < n; ++j) std::swap(M[p * n + j], M[best * n + j]);
-            std::swap(x[p], x[best]);
-        }
-        const RealType piv = M[p * n + p];
-        if (piv == 0.0) throw std::runtime_error("singular system");
-        for (size_t i = p + 1; i < n; ++i) {
-            const RealType m = M[i * n + p] / piv;
-            if (m == 0.0) continue;
-            for (size_t j = p; j < n; ++j) M[i * n + j] -= m * M[p * n + j];
-            x[i] -= m * x[p];
-        }
+    std::vector<int64_t> krow(n, -1);                 // row -> row of the SPD block, -1 for the rows of active cells
+    std::vector<size_t> active;
+    size_t r = 0;
+    for (size_t i = 0; i < n; ++i) {
+        bool has_multiplier = false;
+        for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) has_multiplier = has_multiplier || (size_t)A.colind[k] >= nk;
+        if (has_multiplier) active.push_back(i); else krow[i] = (int64_t)r++;
     }
-    for (size_t ii = n; ii-- > 0;) {
-        RealType s = x[ii];
-        for (size_t j = ii + 1; j < n; ++j) s -= M[ii * n + j] * x[j];
-        x[ii] = s / M[ii * n + ii];
+    if (r != nk) throw std::runtime_error("obstacle system: the block of inactive cells and faces is not square");
+    proton_amd::sparse_matrix<RealType> K;
+    K.nrows = K.ncols = nk;
+    K.rowptr.assign(nk + 1, 0);
+    std::vector<RealType> bk(nk);
+    for (size_t i = 0; i < n; ++i) {
+        if (krow[i] < 0) continue;
+        for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) { K.colind.push_back(A.colind[k]); K.values.push_back(A.values[k]); }
+        K.rowptr[krow[i] + 1] = (int64_t)K.colind.size();
+        bk[krow[i]] = b[i];
+    }
+    cg_params<RealType> cgp;
+    cgp.convergence_threshold = 1e-13; cgp.max_iter = 20 * nk; cgp.apply_preconditioner = true;
+    std::vector<RealType> y;
+    size_t iters = 0;
+    if (conjugated_gradient(K, bk, y, cgp, &iters) != cg_exit_reason::CONVERGED) throw std::runtime_error("obstacle system: CG did not converge");
+    std::vector<RealType> x(n, 0.0);
+    for (size_t j = 0; j < nk; ++j) x[j] = y[j];
+    for (size_t i : active) {                         // beta = b_i - sum_j A_ij y_j, at the row's multiplier column
+        RealType s = b[i];
+        size_t col = n;
+        for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+            if ((size_t)A.colind[k] >= nk) col = (size_t)A.colind[k];
+            else s -= A.values[k] * y[A.colind[k]];
+        }
+        x[col] = s;
     }
     return x;
 }
@@ -50,7 +67,8 @@ int main(int argc, char **argv)
 {
     const size_t degree = argc > 1 ? std::atoi(argv[1]) : 1;
     const size_t N = argc > 2 ? std::atoi(argv[2]) : 8;
-    const bool batched = argc > 3;
+    const bool batched = argc > 3 && std::string(argv[3]) == "batched";
+    const size_t max_outer = argc > 4 ? std::atoi(argv[4]) : 50;               // obstacle.cpp:119: while (iter < 50)
 
     mesh_init_params<RealType> mip;                                         // obstacle.cpp:234-238,276
     mip.Nx = N; mip.Ny = N;
@@ -91,7 +109,8 @@ int main(int argc, char **argv)
     }
 
     size_t iter = 0;
-    for (; iter < 50; ++iter) {
+    bool converged = false;
+    for (; iter < max_outer; ++iter) {
         std::vector<bool> in_A(num_cells);
         for (size_t i = 0; i < num_cells; ++i) in_A[i] = (beta[i] + c * (alpha[i] - gamma[i])) < 0;     // obstacle.cpp:133-142
 
@@ -109,23 +128,34 @@ int main(int argc, char **argv)
         }
         assembler.finalize();
 
-        const auto sol = dense_solve(assembler.LHS, assembler.RHS);
+        size_t num_A = 0;
+        for (size_t i = 0; i < num_cells; ++i) num_A += in_A[i] ? 1 : 0;
+        const auto sol = block_solve(assembler.LHS, assembler.RHS, assembler.RHS.size() - num_A);
         const auto alpha_prev = alpha;
         assembler.expand_solution(msh, sol, bcs_fun, gamma, alpha, beta);
         RealType d2 = 0.0;
         for (size_t i = 0; i < alpha.size(); ++i) d2 += (alpha_prev[i] - alpha[i]) * (alpha_prev[i] - alpha[i]);
-        if (std::sqrt(d2) < 1e-7) break;                                    // obstacle.cpp:193
+        if (std::sqrt(d2) < 1e-7) { converged = true; break; }              // obstacle.cpp:193
     }
 
     RealType error = 0.0;                                                   // obstacle.cpp:202-213
+    std::vector<RealType> proj_all;
+    if (batched) proj_all = project_function_all(msh, hdi, sol_fun, quadrature_degree_increase);      // one device batch
     for (auto &cl : msh.cells) {
         auto local = take_local_data(msh, cl, hdi, alpha);
-        auto proj = project_function(msh, cl, hdi, sol_fun, quadrature_degree_increase);
+        proton_amd::dense_matrix<RealType> proj;
+        if (batched) {
+            proj = proton_amd::dense_matrix<RealType>(local.rows(), 1);
+            std::memcpy(proj.data(), proj_all.data() + offset(msh, cl) * local.rows(), local.rows() * sizeof(RealType));
+        } else {
+            proj = project_function(msh, cl, hdi, sol_fun, quadrature_degree_increase);
+        }
         auto gr = make_hho_laplacian(msh, cl, hdi);
         auto lc = gr.second + make_hho_fancy_stabilization(msh, cl, gr.first, hdi);
         auto diff = local - proj;
         error += diff.dot(lc * diff);
     }
-    std::printf("N %zu degree %zu iterations %zu error %.10e\n", N, degree, iter + 1, std::sqrt(error));
+    std::printf("N %zu degree %zu iterations %zu error %.10e converged %d\n", N, degree, iter + (converged ? 1 : 0), std::sqrt(error),
+                converged ? 1 : 0);
     return 0;
 }

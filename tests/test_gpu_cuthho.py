@@ -289,3 +289,50 @@ def test_interface_assembler_without_cut_cells_is_the_plain_assembler(asm):
     # uncut operators of the cutHHO driver == fan quadrature + naive stabilization of the plain path
     lc = asm.local_ops(k + 1, k, pa.QUAD_FAN, pa.STAB_NAIVE, want=("lc",))["lc"]
     assert torch.equal(lc, ops["lc"])
+
+
+def test_config3_at_full_size_cut_cells_merged(asm, oracle):
+    """configs[2] of BASELINE.json at its own size: cuthho_square -M 512 -N 512 -k 2 -r 4 -f (circle r = 0.35, node
+    displacement).  pa_cut_preprocess -> uncut kernels (fan quadrature, naive stabilization) + cut kernel ->
+    pa_cut_merge (cuthho_square.cpp:883-900): the classification equals the oracle's cell for cell, every merged local
+    matrix is symmetric, cells outside the domain carry a zero right-hand side (cuthho_square.cpp:659-664), and sampled
+    cut and uncut cells match the oracle's operators (cuthho_square.cpp:308-388, 566-621, 623-666)."""
+    import torch
+    from proton_amd.batch import to_rowcol
+    N, k = 512, 2
+    ncut = asm.cut_preprocess(N, refsteps=4)
+    ref = oracle.CutMesh(N, refsteps=4)
+    assert np.array_equal(asm.cell_loc, ref.cell_loc)
+    cut_cells = np.nonzero(ref.cell_loc == oracle.CUT_ON_INTERFACE)[0]
+    assert ncut == len(cut_cells) and 1300 < ncut < 1600, ncut          # ~ perimeter / h cells on the interface
+    lc, rhs = asm.fictdom_local_ops(k)
+    asm.synchronize()
+    assert lc.shape[0] == N * N and bool(torch.isfinite(lc).all()) and bool(torch.isfinite(rhs).all())
+    scale = lc.abs().amax(dim=(1, 2))
+    asym = (lc - lc.transpose(1, 2)).abs().amax(dim=(1, 2)) / scale
+    is_cut = torch.from_numpy(ref.cell_loc == oracle.CUT_ON_INTERFACE).to(lc.device)
+    assert float(asym[~is_cut].max()) < 1e-12
+    assert float(asym[is_cut].max()) < 1e-9          # slivers: cond * eps of the Nitsche-penalised system (see the test above)
+    outside = torch.from_numpy(ref.cell_loc == oracle.CUT_POS).to(lc.device)
+    assert int(outside.sum()) > 0 and float(rhs[outside].abs().max()) == 0.0
+    assert float(rhs[~outside].abs().amax(dim=1).min()) > 0.0
+    di = oracle.degrees(k + 1, k)
+    rng = np.random.default_rng(512)
+    sample_cut = np.sort(rng.choice(cut_cells, size=96, replace=False))
+    uncut = np.nonzero(ref.cell_loc != oracle.CUT_ON_INTERFACE)[0]
+    sample_uncut = np.sort(rng.choice(uncut, size=256, replace=False))
+    lch, rhsh = to_rowcol(lc[torch.from_numpy(np.r_[sample_cut, sample_uncut]).to(lc.device)]), rhs.cpu().numpy()
+    errs = []
+    for i, c in enumerate(np.r_[sample_cut, sample_uncut]):
+        st, o_oper, o_data = ref.laplacian(int(c), di)
+        assert st == 0
+        st, o_stab = ref.cut_stabilization(int(c), di)
+        st, o_rhs = ref.rhs(int(c), di.cell_deg)
+        e = nerr(lch[i], o_data + o_stab)
+        if i < len(sample_cut):
+            errs.append(e)
+            assert e < 5e-9, (int(c), e)
+        else:
+            assert e < TOL, (int(c), e)
+        assert np.abs(rhsh[c] - o_rhs).max() < 1e-12 * max(1.0, np.abs(o_rhs).max())
+    assert np.median(errs) < 1e-11, np.median(errs)

@@ -241,15 +241,19 @@ def test_generated_mesh_matches_reference_generator(asm, oracle):
     assert nerr_cells(to_rowcol(out["lc"]), ref["lc"][3 * N:7 * N]) < TOL
 
 
-@pytest.mark.parametrize("N,cd,fd", [(1024, 3, 2), (256, 2, 1), (512, 0, 1)])
-def test_full_size_properties(asm, oracle, N, cd, fd):
+@pytest.mark.parametrize("N,cd,fd,kind,stabname", [(1024, 3, 2, "tensor", "fancy"), (256, 2, 1, "tensor", "fancy"), (512, 0, 1, "tensor", "fancy"),
+                                                    (256, 2, 1, "fan", "naive"),       # configs[1]: cuthho_square -M 256 -N 256 -k 1, uncut cells
+                                                    (512, 3, 2, "fan", "naive")])      # configs[2] without its cut cells (those: test_gpu_cuthho.py)
+def test_full_size_properties(asm, oracle, N, cd, fd, kind, stabname):
     """BASELINE.json sizes: properties that do not need the oracle on every cell.
     lc is symmetric, annihilates the interpolant of constants (cell dofs (1,0..), face dofs (1,0..)),
     and on the uniform generator mesh every cell equals the oracle's cell 0 up to rounding."""
     import torch
     import proton_amd as pa
+    QUAD = pa.QUAD_TENSOR if kind == "tensor" else pa.QUAD_FAN
+    STAB = pa.STAB_FANCY if stabname == "fancy" else pa.STAB_NAIVE
     asm.generate_mesh(N, N)
-    out = asm.local_ops(cd, fd, pa.QUAD_TENSOR, pa.STAB_FANCY, want=("lc", "info"))
+    out = asm.local_ops(cd, fd, QUAD, STAB, want=("lc", "info"))
     asm.synchronize()
     lc = out["lc"]
     assert int(out["info"].abs().max().cpu()) == 0
@@ -263,14 +267,14 @@ def test_full_size_properties(asm, oracle, N, cd, fd):
         one[di.cbs + f * di.fbs] = 1.0
     assert float(((lc @ one).abs().amax(dim=1) / scale).max()) < 1e-11
     mp, points, ptids = oracle.make_mesh(N, N)
-    st, ref = oracle.local_ops_batch(points, ptids, di, pa.QUAD_TENSOR, pa.STAB_FANCY, first=0, n=1, want=("lc",))
+    st, ref = oracle.local_ops_batch(points, ptids, di, QUAD, STAB, first=0, n=1, want=("lc",))
     ref0 = torch.from_numpy(ref["lc"][0].T.copy()).to(lc.device)
     err = (lc - ref0).abs().amax(dim=(1, 2)) / ref0.abs().max()
     assert float(err.max()) < 1e-10        # coordinates i*h differ in the last bits from cell to cell
     # a few scattered cells against the oracle proper
     idx = [0, 1, N - 1, N * N // 2 + 17, N * N - 1]
     for c in idx:
-        st, r = oracle.local_ops_batch(points, ptids, di, pa.QUAD_TENSOR, pa.STAB_FANCY, first=c, n=1, want=("lc",))
+        st, r = oracle.local_ops_batch(points, ptids, di, QUAD, STAB, first=c, n=1, want=("lc",))
         got = lc[c].cpu().numpy().T
         assert nerr(got, r["lc"][0]) < TOL
 
