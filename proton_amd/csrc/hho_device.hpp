@@ -98,7 +98,7 @@
 // diagnostic build (-DPA_STAGE_CLOCK): shader-clock stamps at the stage boundaries, summed per block over its cells
 // and written to LocalOpsArgs::dbg[block][stage]; PA_TICK(i) closes stage i
 #ifdef PA_STAGE_CLOCK
-#define PA_NSTAGE 12
+#define PA_NSTAGE 16
 #define PA_TICK(i) do { const long long t_ = clock64(); tk_sum[i] += t_ - tk_last; tk_last = t_; } while (0)
 #else
 #define PA_TICK(i)
@@ -1211,6 +1211,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 if (NR & 1) col[NR - 1] += lr[NR - 1];
             }
         } else if (!(a.ablate & 16u)) lds_forward<NR, LD>(LG, col);
+        PA_TICK(11);
         // The trace columns are formed only now (not next to the gr_rhs columns in S3b): they stay
         // out of the register budget of the factorization.  They read the face tables of region Q,
         // which Z overwrites: Y goes to LDS after the barrier below.
@@ -1245,6 +1246,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 for (int k = 0; k < FBS; ++k) uval[r][k] = su * x[k];
             }
         }
+        PA_TICK(12);
         double ucol[C::HAS_STAB ? NF : 1];
 #pragma unroll
         for (int r = 0; r < (C::HAS_STAB ? NF : 1); ++r) ucol[r] = 1.0;
@@ -1553,6 +1555,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                     wave_sync();
                 }
                 }
+                PA_TICK(13);
                 if (badc && !bad) bad = 200 + badc;
                 if (a.uF == nullptr) {
                     // Schur complement, row i' = l - CBS of it by lane l: entries (m', i'), m' <= i', are the run
@@ -1606,6 +1609,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                     if (frow) stg[C::NSP + ip] = gi;
                     }
                     wave_sync();
+                    PA_TICK(14);
                     if (valid && a.cond != nullptr) {
                         double *o = a.cond + (cell - a.first) * (size_t)C::NCOND;
                         static_assert(C::NCOND % 2 == 0, "16-byte stores of the packed record");
