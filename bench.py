@@ -375,6 +375,7 @@ def main():
     torch.cuda.set_device(local_rank)
     comm = None
     host_exchange = None
+    rccl_error = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # torch.distributed carries the bootstrap (RCCL unique id), the barriers and the max over ranks of the timings;
@@ -385,15 +386,37 @@ def main():
     r0, r1 = row_partition(N, world, rank)
     pipe = Pipeline(torch, pa, w, mode, (r0, r1), N, local_rank)
     if world > 1 and mode == "C":
+        from proton_amd.partition import HostStagedHalo
+        if not rehearsal:
+            try:
+                ids = [pa.capi.comm_unique_id() if rank == 0 else None]
+            except Exception as e:       # noqa: BLE001  (reported in the JSON line, never silent)
+                ids, rccl_error = [None], repr(e)
+            dist.broadcast_object_list(ids, src=0)
+            if ids[0] is not None:
+                try:
+                    comm = pa.capi.Comm(pipe.asm.ctx, world, rank, ids[0])
+                except Exception as e:   # noqa: BLE001
+                    rccl_error = repr(e)
+            else:
+                rccl_error = rccl_error or "rank 0 could not create an RCCL unique id"
+            # every rank must take the same transport: if RCCL did not come up on ALL of them the step's exchange goes
+            # through host copies over gloo instead -- the same buffers, the same protocol, labelled as such in `config.exchange`
+            ok = torch.tensor([0 if rccl_error else 1])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 0:
+                errs = [None] * world
+                dist.all_gather_object(errs, rccl_error)
+                rccl_error = "; ".join("rank %d: %s" % (r, e) for r, e in enumerate(errs) if e) or "unknown"
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                rehearsal = True
+            else:
+                pipe.comm = comm
         if rehearsal:
-            from proton_amd.partition import HostStagedHalo
             host_exchange = HostStagedHalo(rank, world)
             pipe.host_exchange = host_exchange
-        else:
-            ids = [pa.capi.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = pa.capi.Comm(pipe.asm.ctx, world, rank, ids[0])
-            pipe.comm = comm
         dist.barrier()                                     # communicators exist before anything is timed
 
     elapsed = timed(torch, dist, world, pipe.step, args.steps, args.warmup)
@@ -442,7 +465,8 @@ def main():
         if world > 1 and mode == "C":
             exch = ("packed top-face rows of each slab's top cell row, one slab up (%d cells x %d doubles = %.2f MB per rank and step), %s"
                     % (N, pipe.ci.halo_doubles, N * pipe.ci.halo_doubles * 8 / 1e6,
-                       "host-staged gloo (REHEARSAL, not RCCL)" if rehearsal else "RCCL send/recv through pa_comm_halo_exchange_start"))
+                       ("host-staged gloo (NOT RCCL%s)" % ((": RCCL failed to initialise -- " + rccl_error) if rccl_error else ", --backend gloo rehearsal"))
+                       if rehearsal else "RCCL send/recv through pa_comm_halo_exchange_start"))
         res = {
             "metric": BASELINE_METRIC,
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
