@@ -187,7 +187,8 @@ def cpu_baseline(w, sample_rows, target_seconds=6.0):
                             "unit": "cells/s",
                             "what": "the span the reference prints as \"Matrix assembly\" (cuthho_square.cpp:881-905): make_assembler + "
                                     "per-cell operators + rhs + assembler.assemble + finalize (setFromTriplets)"},
-        "sample": "first %d (1 thread) / %d (%d threads, OpenMP over cells) of %d cell rows of the same mesh: %.1f + %.1f s and %.1f + %.1f s; "
+        "sample": "a strip of %d (1 thread) / %d (%d threads, OpenMP over cells) of the mesh's %d cell rows, assembled as a mesh of its own "
+                  "(same cells; tables, right-hand side and finalize at their per-cell cost): %.1f + %.1f s and %.1f + %.1f s; "
                   "`value` = per-cell operators + rhs, one thread (the reference is single-threaded); oracle/hho_oracle.c, gcc -O3 -mavx"
                   % (rows, rows_all, cores, N, one["seconds_ops"], one["seconds_assembly"], allc["seconds_ops"], allc["seconds_assembly"]),
     })

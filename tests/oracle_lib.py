@@ -578,16 +578,20 @@ def max_threads():
 
 
 def matrix_assembly_timed(N, di, quad, stab, rows, rhs_fn=1, bcs_fn=2, rhs_di=0, lo=(0.0, 0.0), hi=(1.0, 1.0), nthreads=1):
-    """The reference's "Matrix assembly" span (cuthho_square.cpp:881-905) on cell rows [rows[0], rows[1]) of the N x N
-    generator mesh -> dict(seconds_ops, seconds_assembly, cells, nnz, checksum)"""
-    mp = MeshParams(N, N, lo[0], hi[0], lo[1], hi[1])
+    """The reference's "Matrix assembly" span (cuthho_square.cpp:881-905) on a bounded sample of the N x N generator
+    mesh: the strip of its cell rows [rows[0], rows[1]) as a mesh of its own (N x (rows[1] - rows[0]) cells of the same
+    size and shape, assembled completely -- so that the assembler's tables, the right-hand side and finalize cost what
+    they cost per cell on the full mesh) -> dict(seconds_ops, seconds_assembly, cells, nnz, checksum)"""
+    nrows = rows[1] - rows[0]
+    hy = (hi[1] - lo[1]) / N
+    mp = MeshParams(N, nrows, lo[0], hi[0], lo[1] + rows[0] * hy, lo[1] + rows[1] * hy)
     sec = (C.c_double * 2)()
     nnz, cs = C.c_size_t(0), C.c_double(0.0)
-    st = lib().hho_matrix_assembly_timed(C.byref(mp), rows[0], rows[1], di, quad, stab, rhs_fn, bcs_fn, rhs_di, nthreads, sec,
+    st = lib().hho_matrix_assembly_timed(C.byref(mp), 0, nrows, di, quad, stab, rhs_fn, bcs_fn, rhs_di, nthreads, sec,
                                          C.byref(nnz), C.byref(cs))
     if st not in (0,):
         raise RuntimeError("hho_matrix_assembly_timed: status %d" % st)
-    return {"seconds_ops": sec[0], "seconds_assembly": sec[1], "cells": (rows[1] - rows[0]) * N, "nnz": nnz.value,
+    return {"seconds_ops": sec[0], "seconds_assembly": sec[1], "cells": nrows * N, "nnz": nnz.value,
             "checksum": cs.value}
 
 
