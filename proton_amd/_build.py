@@ -40,7 +40,9 @@ PER_CONFIG_FLAGS = {
     (2, 1, 1): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_WAVES_PER_EU=4"],
     # k = 3 pre-pass: 290 VGPRs leave one wave per SIMD; bounded to 256 it spills 34 (no stores in flight there) and
     # runs two: 258 -> 233 us per 1 M cells
-    (4, 3, 0): ["-DPA_PRE_WAVES=2"],
+    # ... and lc through the LDS image: the direct 8-byte stores of the accumulators made the L2 fetch the partially
+    # written lines (FETCH 3.6 GB against 1.2 GB of records per 1 M cells); full 16-byte runs: 2.93 -> 2.83 ms
+    (4, 3, 0): ["-DPA_PRE_WAVES=2", "-DPA_DIRECT_MIN=99"],
 }
 
 

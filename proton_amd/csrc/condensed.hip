@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void cond_adj_cells_kernel(uint32_t ncells, co
 // of them sits in the face's cells.
 //   code[s] bits 0-1: local face index of column face s in cell A, bit 2: present in A; bits 3-4 / 5: the same for B
 __device__ inline void cond_describe_face(const CondMesh &m, uint32_t f, int32_t &cA, int32_t &cB, int &rowA, int &rowB,
-                                          int32_t (&colcomp)[7], uint8_t (&code)[7], int &ncol)
+                                          int32_t (&colcomp)[7], uint8_t (&code)[7], int &ncol, bool &dirichlet_cols)
 {
+    dirichlet_cols = false;
     int32_t a = m.adj[2 * f], b = m.adj[2 * f + 1];
     if (b == a) b = -1;
     if (a == 0x7fffffff) a = -1;
@@ -84,7 +85,7 @@ __device__ inline void cond_describe_face(const CondMesh &m, uint32_t f, int32_t
                 self = fl == f;
             }
             if (self) { if (side == 0) rowA = lf; else rowB = lf; }
-            if (comp < 0) continue;                                     // Dirichlet: no column (hho.hpp:398)
+            if (comp < 0) { if (c >= 0) dirichlet_cols = true; continue; }      // Dirichlet: no column (hho.hpp:398), its data go to the rhs
             int pos = -1;
             for (int q = 0; q < nc; ++q) if (cand_comp[q] == comp) pos = q;
             if (pos < 0) { pos = nc++; cand_comp[pos] = comp; cand_code[pos] = 0; }
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(256) void cond_symbolic_kernel(CondMesh m, uint32_t
     if (q >= nown) return;
     CondFace r;
     int rowA, rowB, ncol;
-    cond_describe_face(m, f, r.cA, r.cB, rowA, rowB, r.colcomp, r.code, ncol);
+    bool dcols;
+    cond_describe_face(m, f, r.cA, r.cB, rowA, rowB, r.colcomp, r.code, ncol, dcols);
     r.rows = (uint8_t)(rowA | (rowB << 2));
     r.ncol = (uint8_t)ncol;
     r.face = f;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void cond_symbolic_kernel(CondMesh m, uint32_t
     ncols[q] = (uint32_t)ncol;
     CondFaceLean ln;
     ln.cA = r.cA; ln.cB = r.cB;
-    ln.packed = ((uint64_t)r.rows << 42) | ((uint64_t)ncol << 46);
+    ln.packed = ((uint64_t)r.rows << 42) | ((uint64_t)ncol << 46) | ((uint64_t)(dcols ? 1 : 0) << 49);
     for (int s = 0; s < 7; ++s) ln.packed |= (uint64_t)(r.code[s] & 63) << (6 * s);
     lean[q] = ln;
 }
@@ -245,11 +247,21 @@ __global__ __launch_bounds__(256) void cond_rhs_rows_kernel(CondMesh m, uint32_t
     const uint32_t rows = (uint32_t)(r.packed >> 42) & 15u;
     const int nf = 4 * fbs, ncond = nf * (nf + 1) / 2 + nf, hd = fbs * (nf + 1);
     const int rowA = (int)(rows & 3u) * fbs + k, rowB = (int)((rows >> 2) & 3u) * fbs + k;
+    // (bit 49: some face of its local cells is Dirichlet; otherwise a cell's contribution is its g entry alone)
+    const bool dcols = (r.packed >> 49) & 1u;
+    const int og = nf * (nf + 1) / 2;
     double b = 0.0;
     bool have = false;
-    if (r.cA >= 0) { b = cond_rhs_contrib(m, cond + (size_t)r.cA * ncond, r.cA, rowA, fbs, g); have = true; }
-    else if (r.cA <= -2) { b = halo[(size_t)(-2 - r.cA) * hd + fbs * nf + k]; have = true; }
-    if (r.cB >= 0) { const double w = cond_rhs_contrib(m, cond + (size_t)r.cB * ncond, r.cB, rowB, fbs, g); b = have ? b + w : w; }
+    if (r.cA >= 0) {
+        const double *rec = cond + (size_t)r.cA * ncond;
+        b = dcols ? cond_rhs_contrib(m, rec, r.cA, rowA, fbs, g) : rec[og + rowA];
+        have = true;
+    } else if (r.cA <= -2) { b = halo[(size_t)(-2 - r.cA) * hd + fbs * nf + k]; have = true; }
+    if (r.cB >= 0) {
+        const double *rec = cond + (size_t)r.cB * ncond;
+        const double w = dcols ? cond_rhs_contrib(m, rec, r.cB, rowB, fbs, g) : rec[og + rowB];
+        b = have ? b + w : w;
+    }
     rhs[t] = b;
 }
 

@@ -29,7 +29,7 @@ struct CondFace {
 };
 
 // the part of it the numeric phase reads, one 16-byte load: bits 6s .. 6s+5 of `packed`: code[s]; bits 42-45: rows;
-// bits 46-48: ncol
+// bits 46-48: ncol; bit 49: some face of its local cells is Dirichlet (their data enter the right-hand side)
 struct alignas(16) CondFaceLean {
     int32_t cA, cB;
     uint64_t packed;
