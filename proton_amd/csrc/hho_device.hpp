@@ -78,6 +78,10 @@
 #ifndef PA_GRC_MFMA
 #define PA_GRC_MFMA 1
 #endif
+// ... from this many rows of gr_lhs on (14 at k = 3; the 9 of k = 2 measured slower: see DESIGN.md section 6)
+#ifndef PA_GRC_MFMA_MIN_NR
+#define PA_GRC_MFMA_MIN_NR 12
+#endif
 // blocks of one XCD (blockIdx mod 8) take consecutive cells
 #ifndef PA_XCD_MAP
 #define PA_XCD_MAP 1
@@ -1094,7 +1098,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         // points) is one 16 x 16 tile of the matrix pipe per cell, NFP/4 instructions, each lane reading ONE element of
         // either table per step (the vector form reads 4 per 3 FMAs, and the LDS pipeline is the busiest of the kernel).
         // (measured: -5 % at k = 3; nothing at k = 2, where it costs the 4th wave its last registers)
-        constexpr bool GRC_MFMA = C::USE_PRE && SPC > 1 && PA_GRC_MFMA && NR >= 12 && NR <= 16 && CBS <= 16;
+        constexpr bool GRC_MFMA = C::USE_PRE && SPC > 1 && PA_GRC_MFMA && NR >= PA_GRC_MFMA_MIN_NR && NR <= 16 && CBS <= 16;
         if (a.ablate & 4u) {
         } else if (GRC_MFMA) {
             typedef double v4d_ __attribute__((ext_vector_type(4)));
