@@ -269,7 +269,8 @@ int pa_assembler_query(pa_context *ctx, pa_degree_info di, pa_assembler_info *ou
  * PA_FN_SAMPLED d_fvals holds the function at the face quadrature points (nfaces_local x
  * (face_deg+1), the points come from pa_face_quadrature_points). */
 int pa_dirichlet_data_batch(pa_context *ctx, int face_deg, int fn, const double *d_fvals, double *d_g);
-/* integrate(msh, fc, 2*face_deg) quadratures.hpp:404-432: d_xyw[f][face_deg+1][3]; face_deg <= 4
+/* integrate(msh, fc, 2*face_deg) quadratures.hpp:404-432: d_xyw[f][face_deg+1][3]; face_deg <= 7: closed-form rules to
+ * five nodes, golub_welsch's (quadratures.hpp:32-75, ascending nodes) to eight
  * (pass face_deg + di for the points of a degree-increased rule, utils.hpp:185) */
 int pa_face_quadrature_points(pa_context *ctx, int face_deg, double *d_xyw);
 

@@ -53,6 +53,53 @@ double hho_iexp_pow(double x, size_t n)
 }
 
 /* ------------------------------------------------------------------ */
+/* golub_welsch, quadratures.hpp:32-75: nodes = eigenvalues (ascending, the order of Eigen's SelfAdjointEigenSolver) of  */
+/* the Jacobi matrix with off-diagonal sqrt(1 / (4 - 1/i^2)), weights = 2 (first component of the unit eigenvector)^2.  */
+/* The eigen-solve is a cyclic Jacobi iteration on the dense symmetric matrix (n <= 8): the reference's solver is Eigen's */
+/* tridiagonal QR; both deliver eigenpairs to working precision.                                                        */
+/* ------------------------------------------------------------------ */
+int hho_golub_welsch(int n, double *nd, double *wt)
+{
+    double A[HHO_MAX_GAUSS][HHO_MAX_GAUSS], V[HHO_MAX_GAUSS][HHO_MAX_GAUSS];
+    if (n < 1 || n > HHO_MAX_GAUSS) return -HHO_ERR_DEGREE;
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { A[i][j] = 0.0; V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int i = 1; i < n; i++) { double p = 4.0 - 1.0 / ((double)i * i); A[i][i - 1] = A[i - 1][i] = sqrt(1.0 / p); }
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) off += A[i][j] * A[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) {
+                if (A[p][q] == 0.0) continue;
+                double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; k++) {
+                    double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    int order[HHO_MAX_GAUSS];
+    for (int i = 0; i < n; i++) order[i] = i;
+    for (int i = 1; i < n; i++) {                        /* ascending eigenvalues */
+        int o = order[i], j = i - 1;
+        while (j >= 0 && A[order[j]][order[j]] > A[o][o]) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = o;
+    }
+    for (int i = 0; i < n; i++) { nd[i] = A[order[i]][order[i]]; wt[i] = 2.0 * V[0][order[i]] * V[0][order[i]]; }
+    return n;
+}
+
+/* ------------------------------------------------------------------ */
 /* quadratures.hpp:78-158                                              */
 /* ------------------------------------------------------------------ */
 int hho_gauss_legendre(int degree, double *nd, double *wt)
@@ -85,7 +132,8 @@ int hho_gauss_legendre(int degree, double *nd, double *wt)
         qp = sqrt(a1 + a2) / 3.0; qw = (322 - 13.0 * sqrt(70.0)) / 900.0;
         nd[3] = -qp; wt[3] = qw; nd[4] = qp; wt[4] = qw; return 5;
     default:
-        return -HHO_ERR_DEGREE; /* golub_welsch (quadratures.hpp:32-75) not restated */
+        if (n > HHO_MAX_GAUSS) return -HHO_ERR_DEGREE;
+        return hho_golub_welsch(n, nd, wt);
     }
 }
 

@@ -232,7 +232,7 @@ int pa_sizes_for(pa_degree_info di, int quad_kind, pa_sizes *out)
     const int qdeg = 2 * di.rec_deg;
     if (quad_kind == PA_QUAD_TENSOR) {
         const int n = pa::gauss_nodes(qdeg);
-        if (n > 5) return PA_ERR_QUADRATURE;          // would need golub_welsch (quadratures.hpp:32-75)
+        if (n > 5) return PA_ERR_QUADRATURE;          // the local-operator kernels are instantiated for recdeg <= 4 (k <= 3: at most 5 nodes)
         out->cell_qps = n * n;
     } else {
         // quadratures.hpp:245-246 throws above 8; degree 8 itself selects the empty rules[8]
@@ -517,7 +517,7 @@ int pa_dirichlet_data_batch(pa_context *ctx, int face_deg, int fn, const double 
 
 int pa_face_quadrature_points(pa_context *ctx, int face_deg, double *d_xyw)
 {
-    if (!ctx || !d_xyw || face_deg < 0 || face_deg > 4) return PA_ERR_INVALID_ARG;
+    if (!ctx || !d_xyw || face_deg < 0 || face_deg > 7) return PA_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     if (!ctx->d_cell_faces) return PA_ERR_NO_MESH;
     const uint32_t nf = (uint32_t)ctx->nfaces_local;
@@ -964,7 +964,7 @@ extern "C" {
 static int rhs_quadrature(pa_context *ctx, int qdeg, int quad_kind, int *nqp)
 {
     if (quad_kind == PA_QUAD_TENSOR) {
-        if (pa::gauss_nodes(qdeg) > 5) return PA_ERR_QUADRATURE;
+        if (pa::gauss_nodes(qdeg) > 8) return PA_ERR_QUADRATURE;      // tables: closed forms to 5 nodes, golub_welsch's rules to 8
     } else if (quad_kind == PA_QUAD_FAN) {
         if (qdeg > 8) return PA_ERR_QUADRATURE;
     } else return PA_ERR_INVALID_ARG;
@@ -1005,7 +1005,7 @@ int pa_project_function_batch(pa_context *ctx, pa_degree_info di, int quad_kind,
     int st = rhs_quadrature(ctx, qdeg, quad_kind, &nqp);
     if (st != PA_OK) return st;
     const int nfq = di.face_deg + dinc + 1;                         // integrate(msh, fc, 2*(facdeg+di))
-    if (nfq > 5) return PA_ERR_QUADRATURE;
+    if (nfq > 8) return PA_ERR_QUADRATURE;
     if (n == 0) return PA_OK;
     const int cbs = pa::P2(di.cell_deg), msize = cbs + 4 * (di.face_deg + 1);
     st = quad_kind == PA_QUAD_TENSOR

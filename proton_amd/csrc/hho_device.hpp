@@ -124,8 +124,8 @@ struct FaceTables {
     double lft[4][4];     // [j][k] (L^^T)[j][k] = L^[k][j], j <= k
 };
 struct QuadTables {
-    double gauss_x[6][5];
-    double gauss_w[6][5];
+    double gauss_x[9][8];      // up to 8 nodes: closed forms to 5 (quadratures.hpp:96-150), golub_welsch's rules beyond (:32-75)
+    double gauss_w[9][8];
     double dun[9][16][4];
     int dun_n[9];
     FaceTables face[4];

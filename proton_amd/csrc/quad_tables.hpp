@@ -1,8 +1,8 @@
 // quad_tables.hpp -- host-side construction of the quadrature tables the kernels read
 // from __constant__ memory.
 //   Gauss-Legendre: closed forms and emission order of gauss_legendre()
-//                   (src/core/core_bits/quadratures.hpp:78-158); rules with more than five
-//                   nodes (golub_welsch, :32-75) are never requested for k <= 3.
+//                   (src/core/core_bits/quadratures.hpp:78-158); the rules with six to eight nodes
+//                   are golub_welsch's (:32-75): ascending nodes.
 //   Dunavant:       the rules triangle_quadrature() indexes (quadratures.hpp:238-271,
 //                   quadratures_dunavant.hpp:27-130), kept with the reference's 15 printed
 //                   digits, expanded from their symmetry orbits in the reference's row order.
@@ -49,6 +49,26 @@ inline void fill_gauss(QuadTables &t)
         t.gauss_x[5][0] = 0.0; t.gauss_w[5][0] = 128.0 / 225.0;
         t.gauss_x[5][1] = -qi; t.gauss_x[5][2] = qi; t.gauss_w[5][1] = wi; t.gauss_w[5][2] = wi;
         t.gauss_x[5][3] = -qo; t.gauss_x[5][4] = qo; t.gauss_w[5][3] = wo; t.gauss_w[5][4] = wo;
+    }
+    // n = 6 .. 8: what golub_welsch (quadratures.hpp:32-75) returns -- the Gauss-Legendre rule with its nodes in ASCENDING
+    // order (eigenvalues of the Jacobi matrix as Eigen's SelfAdjointEigenSolver lists them).  Reached for quadrature degree
+    // >= 10, i.e. make_rhs / project_function at cell degree 4 with a degree increase; never by the local operators of k <= 3.
+    // Nodes by Newton's iteration on P_n from the Chebyshev guess, weights 2 / ((1 - x^2) P_n'(x)^2): the same numbers as the
+    // reference's eigen-solve to rounding.
+    for (int n = 6; n <= 8; ++n) {
+        for (int i = 0; i < n; ++i) {
+            double x = -std::cos(M_PI * (i + 0.75) / (n + 0.5)), dp = 1.0;
+            for (int it = 0; it < 100; ++it) {
+                double p0 = 1.0, p1 = x;
+                for (int k = 2; k <= n; ++k) { const double p2 = ((2.0 * k - 1.0) * x * p1 - (k - 1.0) * p0) / k; p0 = p1; p1 = p2; }
+                dp = n * (x * p1 - p0) / (x * x - 1.0);
+                const double dx = p1 / dp;
+                x -= dx;
+                if (std::fabs(dx) < 1e-16) break;
+            }
+            t.gauss_x[n][i] = x;
+            t.gauss_w[n][i] = 2.0 / ((1.0 - x * x) * dp * dp);
+        }
     }
 }
 

@@ -394,3 +394,36 @@ def test_obstacle_end_to_end_on_gpu_operators(asm, N, degree):
 
     err, iters = od.run_obstacle(N, degree, local_provider=gpu_provider)
     assert abs(err - REF[N][degree]) / REF[N][degree] < 5e-6
+
+
+@pytest.mark.parametrize("degree", [10, 11, 12, 14, 15])
+def test_gauss_rules_beyond_five_nodes(asm, oracle, degree):
+    """gauss_legendre() hands quadrature degrees >= 10 to golub_welsch (quadratures.hpp:32-75): 6 to 8 nodes in ascending
+    order.  The points of integrate(msh, cl, degree) and integrate(msh, fc, ...) from the product against the oracle's
+    restatement of the eigen-solve (and numpy's Gauss-Legendre rule), and make_rhs / project_function at cell degree 4
+    with a degree increase (quadrature degree 10), which is where a driver meets these rules."""
+    import torch
+    import proton_amd as pa
+    N = 3
+    points, ptids = perturbed_mesh(oracle, N, seed=3)
+    asm.set_mesh(points, ptids)
+    xyw = asm.quadrature_points(degree, pa.QUAD_TENSOR).cpu().numpy()
+    n = ((degree | 1) + 1) // 2
+    assert xyw.shape == (N * N, n * n, 3)
+    L = oracle.lib()
+    nd, wt = np.zeros(8), np.zeros(8)
+    assert L.hho_gauss_legendre(degree, oracle._dp(nd), oracle._dp(wt)) == n
+    gx, gw = np.polynomial.legendre.leggauss(n)
+    assert np.abs(nd[:n] - gx).max() < 5e-15 and np.abs(wt[:n] - gw).max() < 5e-15
+    qx, qy, qw = np.zeros(64), np.zeros(64), np.zeros(64)
+    for c in range(N * N):
+        pts = np.ascontiguousarray(points[ptids[c].astype(np.int64)].reshape(8))
+        nq = L.hho_cell_quadrature(oracle._dp(pts), oracle.QUAD_TENSOR, degree, oracle._dp(qx), oracle._dp(qy), oracle._dp(qw))
+        assert nq == n * n
+        ref = np.stack([qx[:nq], qy[:nq], qw[:nq]], axis=1)
+        assert np.abs(xyw[c] - ref).max() < 1e-14
+    if degree == 10:
+        di = oracle.degrees(4, 3)
+        rhs = asm.cell_rhs(4, pa.capi.FN_SIN_SIN_RHS, pa.QUAD_TENSOR, dinc=1).cpu().numpy()
+        st, ref = oracle.local_ops_batch(points, ptids, di, oracle.QUAD_TENSOR, oracle.STAB_FANCY, fn=1, rhs_di=1, want=("lc",))
+        assert st == 0 and np.abs(rhs - ref["rhs"]).max() < 1e-13 * np.abs(ref["rhs"]).max()

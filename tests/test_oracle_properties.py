@@ -57,11 +57,6 @@ def test_gauss_legendre_exactness(oracle, deg):
         assert nd[0] == 0.0
 
 
-def test_gauss_legendre_needs_eigensolver(oracle):
-    nd, wt = np.zeros(8), np.zeros(8)
-    assert oracle.lib().hho_gauss_legendre(10, oracle._dp(nd), oracle._dp(wt)) < 0
-
-
 def test_dunavant_off_by_one_and_hole(oracle):
     L = oracle.lib()
     p0, p1, p2 = np.array([0.0, 0.0]), np.array([1.0, 0.0]), np.array([0.0, 1.0])
@@ -222,3 +217,20 @@ def test_mesh_closed_forms_match_literal_generator(oracle, Nx, Ny):
                 assert bool(bnd[fid]) == bool(L.hho_mesh_face_is_boundary(C.byref(mp), i, j, lf))
     assert int(bnd.sum()) == 2 * (Nx + Ny)
     assert points[-1] == pytest.approx([1.0, 1.0])
+
+
+def test_golub_welsch_restatement(oracle):
+    """gauss_legendre() beyond five nodes = golub_welsch (quadratures.hpp:32-75): eigenvalues of the Jacobi matrix in
+    ascending order, weights from the first eigenvector components -- the Gauss-Legendre rule, exact to degree 2n - 1."""
+    L = oracle.lib()
+    for degree in range(10, 16):
+        n = ((degree | 1) + 1) // 2
+        nd, wt = np.zeros(8), np.zeros(8)
+        assert L.hho_gauss_legendre(degree, oracle._dp(nd), oracle._dp(wt)) == n
+        x, w = np.polynomial.legendre.leggauss(n)
+        assert np.all(np.diff(nd[:n]) > 0)
+        assert np.abs(nd[:n] - x).max() < 5e-15 and np.abs(wt[:n] - w).max() < 5e-15
+        for p in range(0, 2 * n, 2):                       # exactness on monomials
+            assert abs((wt[:n] * nd[:n] ** p).sum() - 2.0 / (p + 1)) < 1e-14
+    nd, wt = np.zeros(8), np.zeros(8)
+    assert L.hho_gauss_legendre(16, oracle._dp(nd), oracle._dp(wt)) < 0      # 9 nodes: beyond the tables of this restatement
