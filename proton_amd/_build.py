@@ -46,6 +46,11 @@ PER_CONFIG_FLAGS = {
 }
 
 
+if _TAG and os.environ.get("PA_DROP_FLAGS"):          # A/B builds: per-instance settings to leave out
+    _drop = set(os.environ["PA_DROP_FLAGS"].split())
+    PER_CONFIG_FLAGS = {k: [f for f in v if f not in _drop] for k, v in PER_CONFIG_FLAGS.items()}
+
+
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):

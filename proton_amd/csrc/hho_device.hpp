@@ -82,6 +82,14 @@
 #ifndef PA_GRC_MFMA_MIN_NR
 #define PA_GRC_MFMA_MIN_NR 12
 #endif
+// cell columns of gr_rhs from the cell moments (divergence theorem) instead of the face-point tables
+#ifndef PA_LAPG
+#define PA_LAPG 1
+#endif
+// face-basis constants of a lane selected per pass from uniform tables instead of held in registers (fbs <= 3)
+#ifndef PA_FACE_SEL
+#define PA_FACE_SEL 1
+#endif
 // blocks of one XCD (blockIdx mod 8) take consecutive cells
 #ifndef PA_XCD_MAP
 #define PA_XCD_MAP 1
@@ -162,6 +170,12 @@ struct Cfg {
     // The per-cell head is taken from the pre-pass (hho_pre.hpp); for the dense fancy form its record also carries the
     // rows of the cell mass matrix and the Cholesky factor of its leading block (hho.hpp:173-190).
     static constexpr bool USE_PRE = PA_USE_PRE && (PA_PRE_DENSE || !GENERAL_FANCY);
+    // Cell columns of gr_rhs (hho.hpp:64-85): stiff[i, c] - sum_F int_F (grad phi_i . n) phi_c = -int_T phi_c lap(phi_i)
+    // (divergence theorem; both quadratures of the reference are exact for these integrands), i.e. 0, 1 or 2 cell
+    // moments of degree <= recdeg - 2 + celdeg with integer coefficients.  The moments travel with the record.
+    static constexpr bool LAPG = USE_PRE && PA_LAPG;
+    static constexpr int DG = RD - 2 + CD;                    // highest moment degree that is needed
+    static constexpr int NMG = (LAPG && RD >= 2) ? P2(DG) : 0, NMGP = (NMG + 1) & ~1;
     static constexpr int NQB = USE_PRE ? 0 : NQ;              // cell points evaluated by THIS kernel
     static constexpr int NP = NQB + NFP;
     static constexpr int NPW = 2 * RD + 1;                    // powers 0..2 recdeg
@@ -199,7 +213,7 @@ struct Cfg {
     struct Pre {
         static constexpr int NL = (RBS - 1) * RBS / 2;
         static constexpr int oSCAL = (NL + (RBS - 1) + 1) & ~1;
-        static constexpr int NSCAL = 18;                      // ([17]: pivot status of the mass factor)
+        static constexpr int NSCAL = 18 + NMGP;               // ([17]: pivot status of the mass factor; [18..]: moments, LAPG)
         // dense fancy form only: rows i < CBS of the cell mass matrix, [j][i]; packed chol(M1), true diagonal; 1/diagonal
         static constexpr int oMR = oSCAL + NSCAL, NMR = GENERAL_FANCY ? CBS * RBS : 0;
         static constexpr int oMC = oMR + NMR, NMC = GENERAL_FANCY ? CBS * (CBS + 1) / 2 : 0;
@@ -229,7 +243,7 @@ struct Cfg {
     // gr_rhs cell columns are assembled by SPC lanes each (RPP rows per lane) and meet in GRC, which
     // lies on the w*bx^e / by^e tables (dead after the moments)
     // (measured: -1.7 % at k = 2, nothing at k = 3, +1 % with 16 lanes per cell -> only for G = 32)
-    static constexpr int SPC = G >= 32 ? imin(G / CBS, NR) : 1, RPP = cdiv(NR, SPC < 1 ? 1 : SPC);
+    static constexpr int SPC = LAPG ? 1 : G >= 32 ? imin(G / CBS, NR) : 1, RPP = cdiv(NR, SPC < 1 ? 1 : SPC);
     // (with the pre-pass there are no such tables: GRC follows the face tables)
     static constexpr int oGRC = USE_PRE ? endQ0 : 0;          // CBS x NRP
     static constexpr int endQ = endQ0 + (USE_PRE && SPC > 1 ? CBS * NRP : 0);
@@ -257,10 +271,13 @@ struct Cfg {
     // more row are zeroed once per kernel and never written again) and the tail of the record as it comes
     // (reciprocals, scalars), shifted so that the scalars start on a 16-byte boundary
     static constexpr int oLGp = (sizeQ + 1) & ~1;
-    static constexpr int oLIN = ((oLGp + RBS * LD + 1) & ~1) + ((Pre::oSCAL - Pre::NL) & 1);
+    // (the zero row NR behind the image is what the columns without a stiffness part add; not needed with LAPG)
+    static constexpr int LGR = LAPG ? NR : RBS;               // rows of the image of L
+    static constexpr int oLIN = ((oLGp + LGR * LD + 1) & ~1) + ((Pre::oSCAL - Pre::NL) & 1);
     static constexpr int oRCP = oLIN;                         // NR: 1 / L[i][i]
     static constexpr int oSU = USE_PRE ? oLIN + (Pre::oSCAL - Pre::NL) : oSUo;
     static constexpr int oLG = USE_PRE ? oLGp : oST + 1 + LD;  // chol(gr_lhs): stiff[1:,1:] in place without the pre-pass
+    static constexpr int oMG = oSU + 18;                      // NMG moments (LAPG)
     static constexpr int oDUMMY = oSU + (USE_PRE ? Pre::NSCAL : 4);    // 4: sink of masked-out stores
     // dense fancy form on the pre-pass: mass rows, image of chol(M1) (row-major, stride LDM), its reciprocals, trace table
     static constexpr int LDM = (CBS + 1) & ~1;
@@ -804,11 +821,28 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
     const bool is_col = l < MS, is_cellcol = l < CBS;
     const int c0 = is_col ? l : 0;
     const int fc = is_cellcol ? 0 : (c0 - CBS) / FBS, kf = is_cellcol ? 0 : (c0 - CBS) % FBS;
-    double fbq[NFQ], ufc[FBS];                  // t_q^kf ; column kf of L^^T
+    // t_q^kf ; column kf of L^^T.  Per lane and cell-invariant: 2 (NFQ + FBS) registers for the whole kernel -- or, where
+    // the tables are small (FACE_SEL), the uniform tables in scalar registers and a select per use from the lane index
+    // of the pass.
+    // (measured: -4 % for the k = 2 tensor lc kernel, which otherwise spills six registers at its 128; +4 % in its
+    // condensed form and at k = 1, where nothing spills)
+    constexpr bool FACE_SEL = PA_FACE_SEL && FBS == 3 && C::CD == 3 && C::QUAD == QUAD_TENSOR && G == 32 && MODE == MODE_LC;
+    double fbq0[NFQ], ufc0[FBS];
+    double fbt[FACE_SEL ? NFQ : 1][FACE_SEL ? FBS : 1], lftt[FACE_SEL ? FBS : 1][FACE_SEL ? FBS : 1];
 #pragma unroll
-    for (int q = 0; q < NFQ; ++q) fbq[q] = tab->face[C::FD].fb[q][kf];
+    for (int q = 0; q < NFQ; ++q) fbq0[q] = FACE_SEL ? 0.0 : tab->face[C::FD].fb[q][kf];
 #pragma unroll
-    for (int j = 0; j < FBS; ++j) ufc[j] = tab->face[C::FD].lft[j][kf];
+    for (int j = 0; j < FBS; ++j) ufc0[j] = FACE_SEL ? 0.0 : tab->face[C::FD].lft[j][kf];
+    if (FACE_SEL) {
+#pragma unroll
+        for (int q = 0; q < NFQ; ++q)
+#pragma unroll
+            for (int k = 0; k < FBS; ++k) fbt[q][k] = tab->face[C::FD].fb[q][k];
+#pragma unroll
+        for (int j = 0; j < FBS; ++j)
+#pragma unroll
+            for (int k = 0; k < FBS; ++k) lftt[j][k] = tab->face[C::FD].lft[j][k];
+    }
 
     // pairs of the cell's pre-pass record this lane moves to LDS, and where their two doubles go
     typedef typename C::Pre PRE;
@@ -864,7 +898,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         }
     };
     if (C::USE_PRE) {
-        for (int e = l; e < RBS * LD; e += G) S[C::oLG + e] = 0.0;
+        for (int e = l; e < C::LGR * LD; e += G) S[C::oLG + e] = 0.0;
         wave_sync();
         rec_issue(lblock * C::CPW);
         rec_deposit();
@@ -881,6 +915,19 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         asm volatile("" : "+v"(l));
         const bool valid = base + g < a.n;
         const size_t cell = a.first + (valid ? base + g : a.n - 1);
+        double fbq[NFQ], ufc[FBS];
+        if (FACE_SEL) {
+            const int kfl = (l >= CBS && l < MS) ? (l - CBS) % FBS : 0;
+#pragma unroll
+            for (int q = 0; q < NFQ; ++q) fbq[q] = kfl == 0 ? fbt[q][0] : (kfl == 1 || FBS < 3) ? fbt[q][FBS > 1 ? 1 : 0] : fbt[q][FBS > 2 ? 2 : 0];
+#pragma unroll
+            for (int j = 0; j < FBS; ++j) ufc[j] = kfl == 0 ? lftt[j][0] : (kfl == 1 || FBS < 3) ? lftt[j][FBS > 1 ? 1 : 0] : lftt[j][FBS > 2 ? 2 : 0];
+        } else {
+#pragma unroll
+            for (int q = 0; q < NFQ; ++q) fbq[q] = fbq0[q];
+#pragma unroll
+            for (int j = 0; j < FBS; ++j) ufc[j] = ufc0[j];
+        }
 
         // ================= S0: geometry (every lane of the group, registers) ==========
         PA_MARK("S0");
@@ -1138,6 +1185,34 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 for (int r = 0; r < RPP; ++r)
                     if (r0 + r < NR) S[C::oGRC + cc * NRP + r0 + r] = acc[r];
             }
+        } else if (C::LAPG) {
+            if (l < CBS) {
+                // -int_T phi_c lap(phi_i) = -(2/h)^2 (a (a-1) MOM(a-2+a', b+b') + b (b-1) MOM(a+a', b-2+b')) for phi_i = bx^a by^b,
+                // phi_c = bx^a' by^b'.  In the graded ordering the moment of phi_c times the monomial m of degree d sits at
+                // c + d (a' + b') + m: one LDS read per monomial of degree <= recdeg - 2, the rest is in registers.
+                constexpr int NDM = RD >= 2 ? P2(RD - 2) : 1;
+                double mc[NDM];
+                int kcv = 0;                                 // a' + b' (per cell from the opaque lane index: no register held)
+#pragma unroll
+                for (int k = 1; k <= C::CD; ++k) kcv += l >= k * (k + 1) / 2 ? 1 : 0;
+                const double *mg = S + C::oMG + l;
+                mc[0] = 0.0;
+#pragma unroll
+                for (int d = 0; d + 2 <= RD; ++d)
+#pragma unroll
+                    for (int bm = 0; bm <= d; ++bm) mc[d * (d + 1) / 2 + bm] = mg[d * kcv + d * (d + 1) / 2 + bm];
+                const double nih2 = -(ih * ih);
+#pragma unroll
+                for (int ki = 1; ki <= RD; ++ki)
+#pragma unroll
+                    for (int ri = 0; ri <= ki; ++ri) {
+                        const int ai = ki - ri, bi = ri, row = ki * (ki + 1) / 2 + ri - 1;
+                        double v = 0.0;
+                        if (ai >= 2) v = (double)(ai * (ai - 1)) * mc[(ki - 2) * (ki - 1) / 2 + bi];
+                        if (bi >= 2) v = __builtin_fma((double)(bi * (bi - 1)), mc[(ki - 2) * (ki - 1) / 2 + bi - 2], v);
+                        col[row] = nih2 * v;
+                    }
+            }
         } else if (l < CBS) {
             if (C::USE_PRE) {
 #pragma unroll
@@ -1203,6 +1278,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         if (C::USE_PRE) {
             if (!(a.ablate & 16u)) {
                 lds_forward_rd<NR, LD>(LG, S + C::oRCP, col);
+                if (!C::LAPG) {
                 // cell column c >= 1: gr_rhs[:, c] = stiff[1:, c] - F_c and L^-1 stiff[1:, c] = L^T e_(c-1): add row c-1 of L
                 // (the image is zero above the diagonal; the other columns add its zero row NR)
                 const double *lr = LG + ((l >= 1 && l < CBS) ? l - 1 : NR) * LD;
@@ -1213,6 +1289,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                     col[i + 1] += v.y;
                 }
                 if (NR & 1) col[NR - 1] += lr[NR - 1];
+                }
             }
         } else if (!(a.ablate & 16u)) lds_forward<NR, LD>(LG, col);
         PA_TICK(11);

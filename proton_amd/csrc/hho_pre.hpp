@@ -32,7 +32,7 @@ struct PreArgs {
 template <class C>
 __global__ __launch_bounds__(64, PA_PRE_WAVES) void hho_cell_pre_kernel(PreArgs a)
 {
-    constexpr int RD = C::RD, RBS = C::RBS, NR = C::NR, NPW = C::NPW, NMOM = C::NMOM;
+    constexpr int RD = C::RD, NR = C::NR, NPW = C::NPW, NMOM = C::NMOM;
     typedef typename C::Pre PL;
     const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= a.n) return;
@@ -139,6 +139,10 @@ __global__ __launch_bounds__(64, PA_PRE_WAVES) void hho_cell_pre_kernel(PreArgs 
             }
         }
     }
+
+    // the moments of degree <= recdeg - 2 + celdeg travel: the consumer forms the cell columns of gr_rhs from them (Cfg::LAPG)
+#pragma unroll
+    for (int e = 0; e < C::NMG; e += 2) put(PL::oSCAL + 18 + e, double2{mom[e], e + 1 < C::NMG ? mom[e + 1 < NMOM ? e + 1 : 0] : 0.0});
 
     // ---- gr_lhs = stiff[1:,1:] from the moments, Cholesky row by row (Eigen's LLT: unpivoted, lower)
     //   stiff(i,j) = ih^2 (a a' MOM(a+a'-2, b+b') + b b' MOM(a+a', b+b'-2))   bases.hpp:170-176, hho.hpp:57-61

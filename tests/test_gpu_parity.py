@@ -6,6 +6,7 @@ Tolerance: 1e-12 normwise per cell, max|A - A*| / max|A*| (BASELINE.md section 5
 """
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -373,7 +374,21 @@ def test_config5_slabs_2048_k3(asm, oracle):
         assert worst_sym < TOL and worst_ker < 1e-10 and worst_ref < 1e-9, (rank, worst_sym, worst_ker, worst_ref)
         c = r0 * N
         st, r = oracle.local_ops_batch(points, ptids, di, pa.QUAD_TENSOR, pa.STAB_FANCY, first=c, n=1, want=("lc",))
-        assert nerr(lc[0].cpu().numpy().T, r["lc"][0]) < TOL
+        got0 = lc[0].cpu().numpy().T
+        e0 = nerr(got0, r["lc"][0])
+        assert e0 < 5 * TOL, (rank, e0)
+        if e0 >= TOL:
+            # h = 1/2048 at k = 3: the entries that vanish on a square come out as +-5e-13 of the scale on EITHER side (the
+            # rounding of x - barycenter), so the two can be 1e-12 apart; such a cell is judged against the 50-digit evaluation
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+            import mpmath as mpm
+            import make_golden as mg
+            P = [(mpm.mpf(float(x)), mpm.mpf(float(y))) for x, y in points[ptids[c].astype(np.int64)]]
+            truth = mg.local_ops(P, [int(v) for v in ptids[c]], cd, fd, "tensor")
+            ref = mg.to_np(truth["data"]) + mg.to_np(truth["fancy"])
+            print("config 5, slab %d: %.2e against the oracle, %.2e (GPU) and %.2e (oracle) against the 50-digit evaluation"
+                  % (rank, e0, nerr(got0, ref), nerr(r["lc"][0], ref)))
+            assert nerr(got0, ref) < TOL, (rank, nerr(got0, ref))
 
 
 @pytest.mark.parametrize("N,degree", [(16, 0), (16, 1), (32, 1)])
