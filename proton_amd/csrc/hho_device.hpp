@@ -1725,15 +1725,22 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 if (a.lc != nullptr && !(a.ablate & 128u)) {
                     wave_sync();
                     if (valid) {
-                        double *o = a.lc + (cell - a.first) * (size_t)(MS * MS);
-                        constexpr int NPAIR = MS * MS / 2;
+                        // (profiling, bit 1024: every pass of a block writes the same two matrices -- the stores without their HBM traffic)
+                        double *o = a.lc + ((a.ablate & 1024u) ? lblock * C::CPW + g : cell - a.first) * (size_t)(MS * MS);
+                        constexpr int NPAIR = MS * MS / 2, NIT = cdiv(NPAIR, G);
+                        // every read of the image first, then the stores: with a read and its store per step the compiler
+                        // reuses one register quad and the steps become a chain of LDS round trips
+                        typedef double v2d_ __attribute__((ext_vector_type(2)));
+                        v2d_ img[NIT];
 #pragma unroll
-                        for (int e0 = 0; e0 < NPAIR; e0 += G) {
-                            const int e = e0 + l;
-                            if (e < NPAIR) {
-                                const double2 v = *reinterpret_cast<const double2 *>(S + C::oOUT + 2 * e);
-                                *reinterpret_cast<double2 *>(o + 2 * e) = v;
-                            }
+                        for (int it = 0; it < NIT; ++it) {
+                            const int e = it * G + l;
+                            img[it] = *reinterpret_cast<const v2d_ *>(S + C::oOUT + 2 * (((it + 1) * G <= NPAIR || e < NPAIR) ? e : 0));
+                        }
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const int e = it * G + l;
+                            if ((it + 1) * G <= NPAIR || e < NPAIR) *reinterpret_cast<v2d_ *>(o + 2 * e) = img[it];
                         }
                         if ((MS * MS) & 1) {
                             if (l == 0) o[MS * MS - 1] = S[C::oOUT + MS * MS - 1];
@@ -1789,14 +1796,18 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             wave_sync();
             if (valid) {
                 double *o = dst + (cell - a.first) * (size_t)(MS * MS);
-                constexpr int NPAIR = MS * MS / 2;
+                constexpr int NPAIR = MS * MS / 2, NIT = cdiv(NPAIR, G);
+                typedef double v2d_ __attribute__((ext_vector_type(2)));
+                v2d_ img[NIT];                             // reads first, then the stores (see the lc-only path)
 #pragma unroll
-                for (int e0 = 0; e0 < NPAIR; e0 += G) {
-                    const int e = e0 + l;
-                    if (e < NPAIR) {
-                        const double2 v = *reinterpret_cast<const double2 *>(S + C::oOUT + 2 * e);
-                        *reinterpret_cast<double2 *>(o + 2 * e) = v;
-                    }
+                for (int it = 0; it < NIT; ++it) {
+                    const int e = it * G + l;
+                    img[it] = *reinterpret_cast<const v2d_ *>(S + C::oOUT + 2 * (((it + 1) * G <= NPAIR || e < NPAIR) ? e : 0));
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int e = it * G + l;
+                    if ((it + 1) * G <= NPAIR || e < NPAIR) *reinterpret_cast<v2d_ *>(o + 2 * e) = img[it];
                 }
                 if ((MS * MS) & 1) {
                     if (l == 0) o[MS * MS - 1] = S[C::oOUT + MS * MS - 1];
