@@ -90,6 +90,10 @@
 #ifndef PA_FACE_SEL
 #define PA_FACE_SEL 1
 #endif
+// corner tile of Z^T Z: U term in closed form, only the Y rows read
+#ifndef PA_CORNER_SHORT
+#define PA_CORNER_SHORT 1
+#endif
 // blocks of one XCD (blockIdx mod 8) take consecutive cells
 #ifndef PA_XCD_MAP
 #define PA_XCD_MAP 1
@@ -844,6 +848,23 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             for (int k = 0; k < FBS; ++k) lftt[j][k] = tab->face[C::FD].lft[j][k];
     }
 
+    // Corner tile of Z^T Z on the vector pipe (msize 17..24): with T_F = [trace_F | 0] its columns are face columns, whose
+    // U parts are -sqrt(|F|/2h) L^^T e_k on the rows of their own face: the U term of an entry is su_F^2 (L^^ L^^T)[ki][kj]
+    // for two columns of one face and nothing otherwise -- a constant per lane; only the Y rows are read from LDS.
+    constexpr bool CORNER_SHORT = C::CORNER_VALU && PA_CORNER_SHORT && C::HAS_STAB && !C::GENERAL_FANCY && PA_UNIT_U && MODE != MODE_SPLIT &&
+                                  CBS <= 16 && !PA_LC_VALU;
+    double cornerT = 0.0;
+    if (CORNER_SHORT && l < C::NCORNER * (C::NCORNER + 1) / 2) {
+        int cj_ = 0;
+        while ((cj_ + 1) * (cj_ + 2) / 2 <= l) ++cj_;
+        const int ci_ = l - cj_ * (cj_ + 1) / 2;
+        const int fi_ = (16 + ci_ - CBS) / FBS, ki_ = (16 + ci_ - CBS) % FBS, fj_ = (16 + cj_ - CBS) / FBS, kj_ = (16 + cj_ - CBS) % FBS;
+        if (fi_ == fj_) {
+#pragma unroll
+            for (int j = 0; j < FBS; ++j) cornerT += tab->face[C::FD].lft[j][ki_] * tab->face[C::FD].lft[j][kj_];
+        }
+    }
+
     // pairs of the cell's pre-pass record this lane moves to LDS, and where their two doubles go
     typedef typename C::Pre PRE;
     int pre_dst[C::PLC][2];
@@ -1458,6 +1479,36 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         PA_TICK(4);
         // region P is free (L, reciprocals, scalars all consumed): next cell's record -- in the condensed mode only after
         // S9, whose image lies over P as well
+        // corner tile on the vector pipe: every group for its own cell, before the image may overwrite Z (and, in its short
+        // form, before the next record replaces the face scales)
+        double corner = 0.0;
+        int cic = 0, cjc = 0;
+        if (C::CORNER_VALU && !SPLIT && !PA_LC_VALU && l < C::NCORNER * (C::NCORNER + 1) / 2 && !(a.ablate & 64u)) {
+#pragma unroll
+            for (int j = 1; j < C::NCORNER; ++j) cjc += l >= j * (j + 1) / 2 ? 1 : 0;
+            cic = l - cjc * (cjc + 1) / 2;                               // cic <= cjc
+            const double *zi = S + C::oZ + (16 + cic) * ZS, *zj = S + C::oZ + (16 + cjc) * ZS;
+            constexpr int NROW = CORNER_SHORT ? NRP : C::ZR;             // (row NR of Z is a zero pad)
+            typedef double v2d_ __attribute__((ext_vector_type(2)));
+            v2d_ pz[NROW / 2], qz[NROW / 2];                             // every read first: one LDS round trip
+#pragma unroll
+            for (int k = 0; k + 1 < NROW; k += 2) {
+                pz[k / 2] = *reinterpret_cast<const v2d_ *>(zi + k);
+                qz[k / 2] = *reinterpret_cast<const v2d_ *>(zj + k);
+            }
+            double s0 = 0.0, s1 = 0.0;
+            if (CORNER_SHORT) {
+                const double su = S[C::oSU + (16 + cic - CBS) / FBS];
+                s0 = cornerT * su * su;
+            }
+#pragma unroll
+            for (int k = 0; k + 1 < NROW; k += 2) {
+                s0 = __builtin_fma(pz[k / 2].x, qz[k / 2].x, s0);
+                s1 = __builtin_fma(pz[k / 2].y, qz[k / 2].y, s1);
+            }
+            if (NROW & 1) s0 = __builtin_fma(zi[NROW - 1], zj[NROW - 1], s0);
+            corner = s0 + s1;
+        }
         if (C::USE_PRE && !COND) rec_deposit();
         // condensed mode: the cell's right-hand side (lanes < CBS) and, for the recovery, its face unknowns (lanes < NF),
         // one value per lane, in flight during the product
@@ -1487,23 +1538,6 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             // no barrier is needed between the cells: the wavefront reads a cell's Z and then overwrites
             // it with the same cell's output image in program order
             wave_sync();      // Z complete (all columns written)
-            // corner tile on the vector pipe: every group for its own cell, before the image may overwrite Z
-            double corner = 0.0;
-            int cic = 0, cjc = 0;
-            if (C::CORNER_VALU && l < C::NCORNER * (C::NCORNER + 1) / 2 && !(a.ablate & 64u)) {
-                while ((cjc + 1) * (cjc + 2) / 2 <= l) ++cjc;
-                cic = l - cjc * (cjc + 1) / 2;                               // cic <= cjc
-                const double *zi = S + C::oZ + (16 + cic) * ZS, *zj = S + C::oZ + (16 + cjc) * ZS;
-                double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int k = 0; k + 1 < C::ZR; k += 2) {
-                    const double2 p = lds_pair(zi + k), q = lds_pair(zj + k);
-                    s0 = __builtin_fma(p.x, q.x, s0);
-                    s1 = __builtin_fma(p.y, q.y, s1);
-                }
-                if (C::ZR & 1) s0 = __builtin_fma(zi[C::ZR - 1], zj[C::ZR - 1], s0);
-                corner = s0 + s1;
-            }
 #pragma unroll
             for (int gi = 0; gi < C::CPW; ++gi) {
                 v4d acc[NPAIRS];
