@@ -33,8 +33,10 @@ if os.environ.get("PA_WAVES_PER_EU"):      # tuning knob: register budget of the
 # Per-instance compiler settings, each measured on the MI355X against the default.
 # No instance may spill: a scratch reload in the store phase waits for every outstanding store (vmcnt(0)).
 PER_CONFIG_FLAGS = {
-    # k = 2 tensor: 128 VGPRs without spills since U is formed by units; lc through the LDS image (-3 %), 4 waves (-2 %)
-    (3, 2, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_DIRECT_MIN=99", "-DPA_WAVES_PER_EU=4"],
+    # k = 2 tensor: lc through the LDS image (-3 %).  Three waves per SIMD: with the table reads of S3b, the rows of L in the
+    # forward substitution and the corner tile fetched in batches (one LDS round trip each instead of one per use) the
+    # kernel wants more than the 128 registers of a fourth wave -- 1.42 ms at 3 waves against 1.54 (9 spills) at 4
+    (3, 2, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_DIRECT_MIN=99"],
     (3, 2, 1): ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
     (2, 1, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_WAVES_PER_EU=4"],
     (2, 1, 1): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_WAVES_PER_EU=4"],

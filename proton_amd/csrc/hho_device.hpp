@@ -88,11 +88,19 @@
 #endif
 // face-basis constants of a lane selected per pass from uniform tables instead of held in registers (fbs <= 3)
 #ifndef PA_FACE_SEL
-#define PA_FACE_SEL 1
+#define PA_FACE_SEL 0
 #endif
 // corner tile of Z^T Z: U term in closed form, only the Y rows read
 #ifndef PA_CORNER_SHORT
 #define PA_CORNER_SHORT 1
+#endif
+// face columns of gr_rhs: the whole table of the face read before the products (k <= 2)
+#ifndef PA_S3B_BATCH
+#define PA_S3B_BATCH 1
+#endif
+// forward substitution Y = L^-1 gr_rhs: doubles of L read per LDS round trip (0: row by row)
+#ifndef PA_FWD_CAP
+#define PA_FWD_CAP 24
 #endif
 // blocks of one XCD (blockIdx mod 8) take consecutive cells
 #ifndef PA_XCD_MAP
@@ -669,6 +677,37 @@ __device__ __forceinline__ void lds_forward_rd(const double *L, const double *rd
         x[i] = s * rd[i];
     }
 }
+// The same in batches of rows: the prefixes (and reciprocals) of a batch's rows are read together, one LDS round trip per
+// batch instead of one per row -- with a read next to each use the compiler recycles one register quad and every row waits
+// for its own reads.  CAP = doubles of L per batch (registers: 2 CAP).
+__host__ __device__ constexpr int fwd_batch_end(int b0, int n, int cap)
+{
+    int used = 0, r = b0;
+    while (r < n && (r == b0 || used + 2 * ((r + 1) / 2) <= cap)) { used += 2 * ((r + 1) / 2); ++r; }
+    return r;
+}
+template <int N, int LD, int CAP, int B0 = 0>
+__device__ __forceinline__ void lds_forward_rd_batched(const double *L, const double *rd, double (&x)[N])
+{
+    typedef double v2d_ __attribute__((ext_vector_type(2)));
+    constexpr int B1 = fwd_batch_end(B0, N, CAP), NB = B1 - B0, MP = (B1 + 1) / 2;
+    v2d_ lr[NB][MP > 0 ? MP : 1];
+    double rv[NB];
+#pragma unroll
+    for (int r = B0; r < B1; ++r) {
+#pragma unroll
+        for (int k = 0; k < r; k += 2) lr[r - B0][k / 2] = *reinterpret_cast<const v2d_ *>(L + r * LD + k);   // (k = r - 1: the pair ends on the diagonal)
+        rv[r - B0] = rd[r];
+    }
+#pragma unroll
+    for (int r = B0; r < B1; ++r) {
+        double s = x[r];
+#pragma unroll
+        for (int k = 0; k < r; ++k) s = __builtin_fma(-((k & 1) ? lr[r - B0][k / 2].y : lr[r - B0][k / 2].x), x[k], s);
+        x[r] = s * rv[r - B0];
+    }
+    if constexpr (B1 < N) lds_forward_rd_batched<N, LD, CAP, B1>(L, rd, x);
+}
 template <int N, int LD>
 __device__ __forceinline__ void lds_backward_rd(const double *L, const double *rd, double (&x)[N])
 {
@@ -828,8 +867,8 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
     // t_q^kf ; column kf of L^^T.  Per lane and cell-invariant: 2 (NFQ + FBS) registers for the whole kernel -- or, where
     // the tables are small (FACE_SEL), the uniform tables in scalar registers and a select per use from the lane index
     // of the pass.
-    // (measured: -4 % for the k = 2 tensor lc kernel, which otherwise spills six registers at its 128; +4 % in its
-    // condensed form and at k = 1, where nothing spills)
+    // (measured: -4 % for the k = 2 tensor lc kernel while it ran four waves and spilled six registers at its 128; +4 % in
+    // its condensed form and at k = 1, where nothing spills -- and +3 % at the three waves it runs now: off)
     constexpr bool FACE_SEL = PA_FACE_SEL && FBS == 3 && C::CD == 3 && C::QUAD == QUAD_TENSOR && G == 32 && MODE == MODE_LC;
     double fbq0[NFQ], ufc0[FBS];
     double fbt[FACE_SEL ? NFQ : 1][FACE_SEL ? FBS : 1], lftt[FACE_SEL ? FBS : 1][FACE_SEL ? FBS : 1];
@@ -1263,6 +1302,23 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         if (a.ablate & 4u) {
         } else if (l < CBS) {
         } else {
+            if (PA_S3B_BATCH && NFQ * NRP <= 32) {
+                // every row of the face's table first (one LDS round trip), then the products
+                typedef double v2d_ __attribute__((ext_vector_type(2)));
+                v2d_ dnv[NFQ][NRP / 2];
+#pragma unroll
+                for (int q = 0; q < NFQ; ++q)
+#pragma unroll
+                    for (int i = 0; i < NRP; i += 2)
+                        dnv[q][i / 2] = *reinterpret_cast<const v2d_ *>(S + C::oDN + (fc * NFQ + q) * NRP + i);
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NFQ; ++q) s = __builtin_fma((i & 1) ? dnv[q][i / 2].y : dnv[q][i / 2].x, fbq[q], s);
+                    col[i] = s;
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < NR; ++i) col[i] = 0.0;
 #pragma unroll
@@ -1275,6 +1331,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                     col[i + 1] = __builtin_fma(v.y, fbq[q], col[i + 1]);
                 }
                 if (NR & 1) col[NR - 1] = __builtin_fma(dn[NR - 1], fbq[q], col[NR - 1]);
+            }
             }
         }
         wave_sync();
@@ -1298,7 +1355,8 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         if (!C::USE_PRE && !(a.ablate & 8u)) bad = NR <= 6 ? lds_cholesky_blocked<NR, LD, G>(LG, l) : lds_cholesky<NR, LD, G>(LG, l);
         if (C::USE_PRE) {
             if (!(a.ablate & 16u)) {
-                lds_forward_rd<NR, LD>(LG, S + C::oRCP, col);
+                if (PA_FWD_CAP > 0) lds_forward_rd_batched<NR, LD, PA_FWD_CAP>(LG, S + C::oRCP, col);
+                else lds_forward_rd<NR, LD>(LG, S + C::oRCP, col);
                 if (!C::LAPG) {
                 // cell column c >= 1: gr_rhs[:, c] = stiff[1:, c] - F_c and L^-1 stiff[1:, c] = L^T e_(c-1): add row c-1 of L
                 // (the image is zero above the diagonal; the other columns add its zero row NR)
@@ -1327,25 +1385,30 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         constexpr bool UNIT_U = C::HAS_STAB && !C::GENERAL_FANCY && !SPLIT && PA_UNIT_U;
         constexpr int NU = 4 * CBS, UR = UNIT_U ? cdiv(NU, G) : 1;
         double uval[UR][FBS];
+        double uph[UR][NFQ], usu[UR];
         if (UNIT_U && !(a.ablate & 32u)) {
 #pragma unroll
             for (int r = 0; r < UR; ++r) {
                 const int u = l + r * G;
                 const int uu = ((r + 1) * G <= NU || u < NU) ? u : 0;
                 const int f = uu / CBS, cc = uu - f * CBS;
+#pragma unroll
+                for (int q = 0; q < NFQ; ++q) uph[r][q] = S[C::oPHF + (f * NFQ + q) * RBS + cc];
+                usu[r] = S[C::oSU + f];
+            }
+            // (every read of the units first: one LDS round trip)
+#pragma unroll
+            for (int r = 0; r < UR; ++r) {
                 double x[FBS];
 #pragma unroll
                 for (int k = 0; k < FBS; ++k) x[k] = 0.0;
 #pragma unroll
-                for (int q = 0; q < NFQ; ++q) {
-                    const double ph = S[C::oPHF + (f * NFQ + q) * RBS + cc];
+                for (int q = 0; q < NFQ; ++q)
 #pragma unroll
-                    for (int k = 0; k < FBS; ++k) x[k] += ft.cw[q][k] * ph;
-                }
+                    for (int k = 0; k < FBS; ++k) x[k] += ft.cw[q][k] * uph[r][q];
                 face_forward<FBS>(ft, x);
-                const double su = S[C::oSU + f];
 #pragma unroll
-                for (int k = 0; k < FBS; ++k) uval[r][k] = su * x[k];
+                for (int k = 0; k < FBS; ++k) uval[r][k] = usu[r] * x[k];
             }
         }
         PA_TICK(12);
