@@ -102,6 +102,10 @@
 #ifndef PA_FWD_CAP
 #define PA_FWD_CAP 24
 #endif
+// rows of U ordered so that the second column tile of Z^T Z needs fewer k-steps (see Cfg::UPERM)
+#ifndef PA_UPERM
+#define PA_UPERM 1
+#endif
 // blocks of one XCD (blockIdx mod 8) take consecutive cells
 #ifndef PA_XCD_MAP
 #define PA_XCD_MAP 1
@@ -219,6 +223,12 @@ struct Cfg {
     static constexpr int NCORNER = CBS + 4 * FBS - 16;
     static constexpr bool CORNER_VALU = PA_CORNER_VALU && NCORNER > 0 && NCORNER <= 8 && NCORNER * (NCORNER + 1) / 2 <= G;
 
+    // lc with T_F = [trace_F | 0] and 17..32 columns: the second column tile holds face columns only, of the faces UF1..3,
+    // and the U rows of the other faces are zero in it.  With the rows of those faces FIRST behind Y (a permutation of the
+    // rows of Z does not change Z^T Z) the products of that tile stop after the Y rows and theirs: KS1 k-steps instead of KS.
+    static constexpr bool UPERM = PA_UPERM && HAS_STAB && !GENERAL_FANCY && PA_UNIT_U && CBS <= 16 && CBS + 4 * FBS > 16 && CBS + 4 * FBS <= 32;
+    static constexpr int UF1 = UPERM ? (16 - CBS) / FBS : 0;
+    static constexpr int KS1 = cdiv(((RBS - 1 + 1) & ~1) + (4 - UF1) * FBS, 4);
     // ---- record of a cell written by the pre-pass (doubles): packed lower triangle of L = chol(gr_lhs), row-major,
     // TRUE diagonal | 1/diagonal | pad | sqrt(|F|/2h) x 4, barycenter, 2/h_T, pivot status, the 4 vertices, face
     // orientation bits (bit f: the first vertex of local face f has the HIGHER point id), pad
@@ -1383,6 +1393,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         // column through the same steps with CBS of G lanes useful; the face columns of U are -sqrt(|F|/2h) L^^T E_F,
         // constants times the face's scale.  Nothing of U is held in registers across the stages.
         constexpr bool UNIT_U = C::HAS_STAB && !C::GENERAL_FANCY && !SPLIT && PA_UNIT_U;
+        constexpr bool UPERM_ON = C::UPERM && UNIT_U && !PA_LC_VALU;
         constexpr int NU = 4 * CBS, UR = UNIT_U ? cdiv(NU, G) : 1;
         double uval[UR][FBS];
         double uph[UR][NFQ], usu[UR];
@@ -1462,7 +1473,8 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 const bool on = (r + 1) * G <= NU || u < NU;          // whole rounds: known at compile time
                 const int uu = on ? u : 0;
                 const int f = uu / CBS, cc = uu - f * CBS;
-                double *zu = S + (on ? C::oZ + NRP + f * FBS + cc * ZS : C::oDUMMY);      // (the sink holds 4 doubles)
+                const int ur = (UPERM_ON ? ((f + 4 - C::UF1) & 3) : f) * FBS;           // row block of face f (see Cfg::UPERM)
+                double *zu = S + (on ? C::oZ + NRP + ur + cc * ZS : C::oDUMMY);           // (the sink holds 4 doubles)
 #pragma unroll
                 for (int k = 0; k < FBS; ++k) zu[k] = uval[r][k];
             }
@@ -1475,7 +1487,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 for (int r = 0; r < NF; r += 2) *reinterpret_cast<double2 *>(zc + r) = double2{0.0, 0.0};
                 const double msu = -S[C::oSU + fc];
 #pragma unroll
-                for (int k = 0; k < FBS; ++k) zc[fc * FBS + k] = msu * ufc[k];
+                for (int k = 0; k < FBS; ++k) zc[(UPERM_ON ? ((fc + 4 - C::UF1) & 3) : fc) * FBS + k] = msu * ufc[k];
             }
         }
         if (C::HAS_STAB && !UNIT_U && !(a.ablate & 32u)) {
@@ -1615,6 +1627,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                         double z[NTL];
 #pragma unroll
                         for (int t = 0; t < NTL; ++t) {
+                            if (UPERM_ON && t == 1 && ks >= C::KS1) { z[t] = 0.0; continue; }
                             const int col = 16 * t + jj;
                             // (decided at compile time wherever the whole tile row / k-step is inside Z)
                             const bool ok = (4 * ks + 3 < C::ZR || k < C::ZR) && (16 * t + 15 < MS || col < MS);
@@ -1626,7 +1639,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                         for (int I = 0; I < NTL; ++I)
 #pragma unroll
                             for (int J = I; J < NTL; ++J, ++t)
-                                if (!(C::CORNER_VALU && I == 1 && J == 1))
+                                if (!(C::CORNER_VALU && I == 1 && J == 1) && !(UPERM_ON && J == 1 && ks >= C::KS1))
                                     acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[I], z[J], acc[t], 0, 0, 0);
                     }
                 }
