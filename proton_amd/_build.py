@@ -37,7 +37,9 @@ PER_CONFIG_FLAGS = {
     # forward substitution and the corner tile fetched in batches (one LDS round trip each instead of one per use) the
     # kernel wants more than the 128 registers of a fourth wave -- 1.42 ms at 3 waves against 1.54 (9 spills) at 4
     (3, 2, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_DIRECT_MIN=99"],
-    (3, 2, 1): ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
+    (3, 2, 1): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_FWD_CAP=16"],       # (24 doubles of L per batch: one register spilled)
+    (2, 2, 0): ["-DPA_FWD_CAP=16"],
+    (2, 2, 1): ["-DPA_FWD_CAP=16"],
     (2, 1, 0): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_WAVES_PER_EU=4"],
     (2, 1, 1): ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-DPA_WAVES_PER_EU=4"],
     # k = 3 pre-pass: 290 VGPRs leave one wave per SIMD; bounded to 256 it spills 34 (no stores in flight there) and

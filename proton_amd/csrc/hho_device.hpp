@@ -709,12 +709,14 @@ __device__ __forceinline__ void lds_forward_rd_batched(const double *L, const do
         for (int k = 0; k < r; k += 2) lr[r - B0][k / 2] = *reinterpret_cast<const v2d_ *>(L + r * LD + k);   // (k = r - 1: the pair ends on the diagonal)
         rv[r - B0] = rd[r];
     }
+    // column by column: the updates of a column are independent of each other (written row by row the FMAs of a row are one
+    // dependent chain after the other); every row still sums in ascending k, so the results are those of the row form
 #pragma unroll
-    for (int r = B0; r < B1; ++r) {
-        double s = x[r];
+    for (int k = 0; k < B1; ++k) {
+        if (k >= B0) x[k] *= rv[k - B0];
 #pragma unroll
-        for (int k = 0; k < r; ++k) s = __builtin_fma(-((k & 1) ? lr[r - B0][k / 2].y : lr[r - B0][k / 2].x), x[k], s);
-        x[r] = s * rv[r - B0];
+        for (int r = (k + 1 > B0 ? k + 1 : B0); r < B1; ++r)
+            x[r] = __builtin_fma(-((k & 1) ? lr[r - B0][k / 2].y : lr[r - B0][k / 2].x), x[k], x[r]);
     }
     if constexpr (B1 < N) lds_forward_rd_batched<N, LD, CAP, B1>(L, rd, x);
 }
@@ -1312,21 +1314,25 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         if (a.ablate & 4u) {
         } else if (l < CBS) {
         } else {
-            if (PA_S3B_BATCH && NFQ * NRP <= 32) {
-                // every row of the face's table first (one LDS round trip), then the products
+            if (PA_S3B_BATCH) {
+                // the rows of the face's table in batches of QG points (<= 32 doubles), one LDS round trip each, then the products
                 typedef double v2d_ __attribute__((ext_vector_type(2)));
-                v2d_ dnv[NFQ][NRP / 2];
+                constexpr int QG = imax(1, imin(NFQ, 32 / NRP));
 #pragma unroll
-                for (int q = 0; q < NFQ; ++q)
+                for (int i = 0; i < NR; ++i) col[i] = 0.0;
 #pragma unroll
-                    for (int i = 0; i < NRP; i += 2)
-                        dnv[q][i / 2] = *reinterpret_cast<const v2d_ *>(S + C::oDN + (fc * NFQ + q) * NRP + i);
+                for (int q0 = 0; q0 < NFQ; q0 += QG) {
+                    v2d_ dnv[QG][NRP / 2];
 #pragma unroll
-                for (int i = 0; i < NR; ++i) {
-                    double s = 0.0;
+                    for (int q = q0; q < q0 + QG; ++q)
 #pragma unroll
-                    for (int q = 0; q < NFQ; ++q) s = __builtin_fma((i & 1) ? dnv[q][i / 2].y : dnv[q][i / 2].x, fbq[q], s);
-                    col[i] = s;
+                        for (int i = 0; i < NRP; i += 2)
+                            if (q < NFQ) dnv[q - q0][i / 2] = *reinterpret_cast<const v2d_ *>(S + C::oDN + (fc * NFQ + q) * NRP + i);
+#pragma unroll
+                    for (int i = 0; i < NR; ++i)
+#pragma unroll
+                        for (int q = q0; q < q0 + QG; ++q)
+                            if (q < NFQ) col[i] = __builtin_fma((i & 1) ? dnv[q - q0][i / 2].y : dnv[q - q0][i / 2].x, fbq[q], col[i]);
                 }
             } else {
 #pragma unroll
@@ -1554,35 +1560,17 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         PA_TICK(4);
         // region P is free (L, reciprocals, scalars all consumed): next cell's record -- in the condensed mode only after
         // S9, whose image lies over P as well
-        // corner tile on the vector pipe: every group for its own cell, before the image may overwrite Z (and, in its short
-        // form, before the next record replaces the face scales)
-        double corner = 0.0;
+        // corner tile on the vector pipe, short form: its U term needs the face scale, which the next record is about to replace
+        double cornerU = 0.0;
         int cic = 0, cjc = 0;
-        if (C::CORNER_VALU && !SPLIT && !PA_LC_VALU && l < C::NCORNER * (C::NCORNER + 1) / 2 && !(a.ablate & 64u)) {
+        if (C::CORNER_VALU && !SPLIT && !PA_LC_VALU) {
 #pragma unroll
             for (int j = 1; j < C::NCORNER; ++j) cjc += l >= j * (j + 1) / 2 ? 1 : 0;
             cic = l - cjc * (cjc + 1) / 2;                               // cic <= cjc
-            const double *zi = S + C::oZ + (16 + cic) * ZS, *zj = S + C::oZ + (16 + cjc) * ZS;
-            constexpr int NROW = CORNER_SHORT ? NRP : C::ZR;             // (row NR of Z is a zero pad)
-            typedef double v2d_ __attribute__((ext_vector_type(2)));
-            v2d_ pz[NROW / 2], qz[NROW / 2];                             // every read first: one LDS round trip
-#pragma unroll
-            for (int k = 0; k + 1 < NROW; k += 2) {
-                pz[k / 2] = *reinterpret_cast<const v2d_ *>(zi + k);
-                qz[k / 2] = *reinterpret_cast<const v2d_ *>(zj + k);
-            }
-            double s0 = 0.0, s1 = 0.0;
-            if (CORNER_SHORT) {
+            if (CORNER_SHORT && l < C::NCORNER * (C::NCORNER + 1) / 2) {
                 const double su = S[C::oSU + (16 + cic - CBS) / FBS];
-                s0 = cornerT * su * su;
+                cornerU = cornerT * su * su;
             }
-#pragma unroll
-            for (int k = 0; k + 1 < NROW; k += 2) {
-                s0 = __builtin_fma(pz[k / 2].x, qz[k / 2].x, s0);
-                s1 = __builtin_fma(pz[k / 2].y, qz[k / 2].y, s1);
-            }
-            if (NROW & 1) s0 = __builtin_fma(zi[NROW - 1], zj[NROW - 1], s0);
-            corner = s0 + s1;
         }
         if (C::USE_PRE && !COND) rec_deposit();
         // condensed mode: the cell's right-hand side (lanes < CBS) and, for the recovery, its face unknowns (lanes < NF),
@@ -1613,6 +1601,27 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             // no barrier is needed between the cells: the wavefront reads a cell's Z and then overwrites
             // it with the same cell's output image in program order
             wave_sync();      // Z complete (all columns written)
+            // corner tile on the vector pipe: every group for its own cell, before the image may overwrite Z
+            double corner = 0.0;
+            if (C::CORNER_VALU && l < C::NCORNER * (C::NCORNER + 1) / 2 && !(a.ablate & 64u)) {
+                const double *zi = S + C::oZ + (16 + cic) * ZS, *zj = S + C::oZ + (16 + cjc) * ZS;
+                constexpr int NROW = CORNER_SHORT ? NRP : C::ZR;             // (row NR of Z is a zero pad)
+                typedef double v2d_ __attribute__((ext_vector_type(2)));
+                v2d_ pz[NROW / 2], qz[NROW / 2];                             // every read first: one LDS round trip
+#pragma unroll
+                for (int k = 0; k + 1 < NROW; k += 2) {
+                    pz[k / 2] = *reinterpret_cast<const v2d_ *>(zi + k);
+                    qz[k / 2] = *reinterpret_cast<const v2d_ *>(zj + k);
+                }
+                double s0 = cornerU, s1 = 0.0;
+#pragma unroll
+                for (int k = 0; k + 1 < NROW; k += 2) {
+                    s0 = __builtin_fma(pz[k / 2].x, qz[k / 2].x, s0);
+                    s1 = __builtin_fma(pz[k / 2].y, qz[k / 2].y, s1);
+                }
+                if (NROW & 1) s0 = __builtin_fma(zi[NROW - 1], zj[NROW - 1], s0);
+                corner = s0 + s1;
+            }
 #pragma unroll
             for (int gi = 0; gi < C::CPW; ++gi) {
                 v4d acc[NPAIRS];
