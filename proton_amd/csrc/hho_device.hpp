@@ -106,6 +106,14 @@
 #ifndef PA_UPERM
 #define PA_UPERM 1
 #endif
+// forward / backward substitution with L in registers, broadcast by DPP (see Cfg::DPPFWD)
+#ifndef PA_DPPFWD
+#define PA_DPPFWD 1
+#endif
+// lc through the LDS image: each cell's image stored as soon as it is complete, all 64 lanes on it (measured: +-1 %, off)
+#ifndef PA_EARLY_OUT
+#define PA_EARLY_OUT 0
+#endif
 // blocks of one XCD (blockIdx mod 8) take consecutive cells
 #ifndef PA_XCD_MAP
 #define PA_XCD_MAP 1
@@ -192,6 +200,12 @@ struct Cfg {
     static constexpr bool LAPG = USE_PRE && PA_LAPG;
     static constexpr int DG = RD - 2 + CD;                    // highest moment degree that is needed
     static constexpr int NMG = (LAPG && RD >= 2) ? P2(DG) : 0, NMGP = (NMG + 1) & ~1;
+    // Every lane of a cell reads the SAME element of L in every step of the substitutions Y = L^-1 gr_rhs and L^-T Y: as LDS
+    // reads that is a 16-byte broadcast per two FMAs, a quarter of the kernel's LDS cycles at k = 3 -- and the LDS pipeline is
+    // its busiest unit.  Instead the packed factor (and the reciprocal diagonal) sits in registers, element e in lane e mod 16 of
+    // each row of 16 lanes (ceil((NL + NR) / 16) doubles per lane, one 8-byte LDS read each), and the FMAs take it through the
+    // DPP operand  v_fmac_f64_dpp ... row_newbcast:n  (gfx90a+: lane n of the row of 16, for 64-bit operands).  No image of L.
+    static constexpr bool DPPFWD = LAPG && !GENERAL_FANCY && PA_DPPFWD;
     static constexpr int NQB = USE_PRE ? 0 : NQ;              // cell points evaluated by THIS kernel
     static constexpr int NP = NQB + NFP;
     static constexpr int NPW = 2 * RD + 1;                    // powers 0..2 recdeg
@@ -292,12 +306,15 @@ struct Cfg {
     // region P with the pre-pass: the image of L (NR x LD, row-major, true diagonal; the upper triangle and one
     // more row are zeroed once per kernel and never written again) and the tail of the record as it comes
     // (reciprocals, scalars), shifted so that the scalars start on a 16-byte boundary
+    // ... with DPPFWD: the record as it comes (packed L, reciprocals, scalars, moments), 16-byte pairs in place
+    static constexpr int oREC = (sizeQ + 1) & ~1;
+    static constexpr int NLR = cdiv(Pre::NL + (RBS - 1), 16);   // registers of the packed factor + reciprocals
     static constexpr int oLGp = (sizeQ + 1) & ~1;
     // (the zero row NR behind the image is what the columns without a stiffness part add; not needed with LAPG)
     static constexpr int LGR = LAPG ? NR : RBS;               // rows of the image of L
     static constexpr int oLIN = ((oLGp + LGR * LD + 1) & ~1) + ((Pre::oSCAL - Pre::NL) & 1);
-    static constexpr int oRCP = oLIN;                         // NR: 1 / L[i][i]
-    static constexpr int oSU = USE_PRE ? oLIN + (Pre::oSCAL - Pre::NL) : oSUo;
+    static constexpr int oRCP = DPPFWD ? oREC + Pre::NL : oLIN;      // NR: 1 / L[i][i]
+    static constexpr int oSU = DPPFWD ? oREC + Pre::oSCAL : USE_PRE ? oLIN + (Pre::oSCAL - Pre::NL) : oSUo;
     static constexpr int oLG = USE_PRE ? oLGp : oST + 1 + LD;  // chol(gr_lhs): stiff[1:,1:] in place without the pre-pass
     static constexpr int oMG = oSU + 18;                      // NMG moments (LAPG)
     static constexpr int oDUMMY = oSU + (USE_PRE ? Pre::NSCAL : 4);    // 4: sink of masked-out stores
@@ -720,6 +737,62 @@ __device__ __forceinline__ void lds_forward_rd_batched(const double *L, const do
     }
     if constexpr (B1 < N) lds_forward_rd_batched<N, LD, CAP, B1>(L, rd, x);
 }
+// ---- the same substitutions with the packed factor in registers (Cfg::DPPFWD): element e of [packed L | 1 / diagonal] is
+// held by lane e mod 16 of each row of 16 lanes in lr[e / 16]; an FMA takes it through its DPP operand (row_newbcast).
+// The DPP source registers are written by LDS loads only: the 2 wait states a VALU write would need before a DPP read of
+// the same register never arise (tools/spills.py checks the ISA for it).
+template <int E>
+__device__ __forceinline__ void dpp_fnma(double &acc, double lv, double x)     // acc -= bcast(lv, E) * x
+{
+    asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(lv), "v"(x), "n"(E));
+}
+template <int E>
+__device__ __forceinline__ double dpp_bcast(double lv)                        // bcast(lv, E)
+{
+    double r;
+    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(lv), "n"(E));
+    return r;
+}
+template <int NLR, int E>
+__device__ __forceinline__ void dpp_fnma_e(double &acc, const double (&lr)[NLR], double x) { dpp_fnma<E % 16>(acc, lr[E / 16], x); }
+template <int NLR, int E>
+__device__ __forceinline__ double dpp_bcast_e(const double (&lr)[NLR]) { return dpp_bcast<E % 16>(lr[E / 16]); }
+
+// x = L^-1 x, column by column (the updates of a column are independent FMAs; every row sums in ascending k)
+template <int N, int NLR, int K, int R>
+__device__ __forceinline__ void dpp_forward_col(const double (&lr)[NLR], double (&x)[N])
+{
+    if constexpr (R < N) {
+        dpp_fnma_e<NLR, R * (R + 1) / 2 + K>(x[R], lr, x[K]);
+        dpp_forward_col<N, NLR, K, R + 1>(lr, x);
+    }
+}
+template <int N, int NLR, int K = 0>
+__device__ __forceinline__ void dpp_forward(const double (&lr)[NLR], double (&x)[N])
+{
+    constexpr int NL = N * (N + 1) / 2;
+    x[K] *= dpp_bcast_e<NLR, NL + K>(lr);
+    dpp_forward_col<N, NLR, K, K + 1>(lr, x);
+    if constexpr (K + 1 < N) dpp_forward<N, NLR, K + 1>(lr, x);
+}
+// x = L^-T x: x[K] = (x[K] - sum_{k > K} L[k][K] x[k]) / L[K][K], K descending; column K of L^T is row K of L
+template <int N, int NLR, int K, int I>
+__device__ __forceinline__ void dpp_backward_row(const double (&lr)[NLR], double (&x)[N])
+{
+    if constexpr (I < K) {
+        dpp_fnma_e<NLR, K * (K + 1) / 2 + I>(x[I], lr, x[K]);
+        dpp_backward_row<N, NLR, K, I + 1>(lr, x);
+    }
+}
+template <int N, int NLR, int K = N - 1>
+__device__ __forceinline__ void dpp_backward(const double (&lr)[NLR], double (&x)[N])
+{
+    constexpr int NL = N * (N + 1) / 2;
+    x[K] *= dpp_bcast_e<NLR, NL + K>(lr);
+    dpp_backward_row<N, NLR, K, 0>(lr, x);
+    if constexpr (K > 0) dpp_backward<N, NLR, K - 1>(lr, x);
+}
+
 template <int N, int LD>
 __device__ __forceinline__ void lds_backward_rd(const double *L, const double *rd, double (&x)[N])
 {
@@ -925,7 +998,9 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         for (int h = 0; h < 2; ++h) {
             const int e = 2 * (l + t * G) + h;
             int dst = C::oDUMMY + h;
-            if (e < PRE::NL) {
+            if (C::DPPFWD) {
+                if (e < PRE::NPRE) dst = C::oREC + e;            // the record as it comes
+            } else if (e < PRE::NL) {
                 int i = 0;
                 while ((i + 1) * (i + 2) / 2 <= e) ++i;
                 dst = C::oLG + i * LD + (e - i * (i + 1) / 2);
@@ -965,13 +1040,20 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
     auto rec_deposit = [&]() {
 #pragma unroll
         for (int t = 0; t < C::PLC; ++t) {
-            S[pre_dst[t][0]] = rec[t].x;
-            S[pre_dst[t][1]] = rec[t].y;
+            if (C::DPPFWD) {
+                typedef double v2d_ __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<v2d_ *>(S + pre_dst[t][0]) = v2d_{rec[t].x, rec[t].y};      // (16-byte aligned: oREC, oDUMMY and 2 e are even)
+            } else {
+                S[pre_dst[t][0]] = rec[t].x;
+                S[pre_dst[t][1]] = rec[t].y;
+            }
         }
     };
     if (C::USE_PRE) {
-        for (int e = l; e < C::LGR * LD; e += G) S[C::oLG + e] = 0.0;
-        wave_sync();
+        if (!C::DPPFWD) {
+            for (int e = l; e < C::LGR * LD; e += G) S[C::oLG + e] = 0.0;
+            wave_sync();
+        }
         rec_issue(lblock * C::CPW);
         rec_deposit();
         wave_sync();
@@ -1365,13 +1447,18 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         PA_TICK(2);
         PA_MARK("S4");
         double *LG = S + C::oLG;                 // without the pre-pass: stiff[1:,1:], symmetric: row-major == column-major
+        double lreg[C::NLR];                     // DPPFWD: [packed L | 1 / diagonal], element e in lane e mod 16 of a row, register e / 16
         int bad = bad_pre;
         // blocked form where its extra registers are free (measured: -3 % at k = 1; +4 % at k = 2, where it
         // pushes the kernel into spills)
         if (!C::USE_PRE && !(a.ablate & 8u)) bad = NR <= 6 ? lds_cholesky_blocked<NR, LD, G>(LG, l) : lds_cholesky<NR, LD, G>(LG, l);
         if (C::USE_PRE) {
             if (!(a.ablate & 16u)) {
-                if (PA_FWD_CAP > 0) lds_forward_rd_batched<NR, LD, PA_FWD_CAP>(LG, S + C::oRCP, col);
+                if (C::DPPFWD) {
+#pragma unroll
+                    for (int t = 0; t < C::NLR; ++t) lreg[t] = S[C::oREC + (lane & 15) + 16 * t];      // (reads past NL + NR stay inside the record)
+                    dpp_forward<NR, C::NLR>(lreg, col);
+                } else if (PA_FWD_CAP > 0) lds_forward_rd_batched<NR, LD, PA_FWD_CAP>(LG, S + C::oRCP, col);
                 else lds_forward_rd<NR, LD>(LG, S + C::oRCP, col);
                 if (!C::LAPG) {
                 // cell column c >= 1: gr_rhs[:, c] = stiff[1:, c] - F_c and L^-1 stiff[1:, c] = L^T e_(c-1): add row c-1 of L
@@ -1460,7 +1547,8 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
 #pragma unroll
         for (int k = 0; k < NR; ++k) ycol[k] = col[k];
         if (C::GENERAL_FANCY || a.oper != nullptr) {
-            if (C::USE_PRE) lds_backward_rd<NR, LD>(LG, S + C::oRCP, col);
+            if (C::DPPFWD) dpp_backward<NR, C::NLR>(lreg, col);
+            else if (C::USE_PRE) lds_backward_rd<NR, LD>(LG, S + C::oRCP, col);
             else lds_backward<NR, LD>(LG, col);            // col = oper[:, c]
             if (a.oper != nullptr && valid && l < MS) {
                 double *dst = a.oper + (cell - a.first) * (size_t)(NR * MS) + (size_t)c * NR;
@@ -1596,6 +1684,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             typedef double v4d __attribute__((ext_vector_type(4)));
             const int kk = lane >> 4, jj = lane & 15;
             constexpr bool DIRECT = C::DIRECT_STORE && !COND;      // condensed mode: always through the LDS image
+            constexpr bool EARLY_OUT = PA_EARLY_OUT && !DIRECT && !COND && C::CPW > 1;
             constexpr int OS = COND ? C::LDI : MS;                 // stride of the image
             const bool want_image = COND || a.lc != nullptr;
             // no barrier is needed between the cells: the wavefront reads a cell's Z and then overwrites
@@ -1702,10 +1791,36 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                             }
                         }
                 }
+                // lc only: the image of cell gi goes out at once, all 64 lanes on it (1 KB per store instruction), while the
+                // matrix instructions of the next cell run -- not both cells in one burst of stores at the end of the pass
+                if (EARLY_OUT && a.lc != nullptr && !(a.ablate & 128u)) {
+                    if (C::CORNER_VALU && g == gi && l < C::NCORNER * (C::NCORNER + 1) / 2) {
+                        Og[(16 + cic) + (16 + cjc) * OS] = corner;
+                        Og[(16 + cjc) + (16 + cic) * OS] = corner;
+                    }
+                    wave_sync();
+                    if (base + gi < a.n) {
+                        double *o = a.lc + ((a.ablate & 1024u) ? lblock * C::CPW + gi : base + gi) * (size_t)(MS * MS);
+                        constexpr int NPAIR = MS * MS / 2, NIT = cdiv(NPAIR, 64);
+                        typedef double v2d_ __attribute__((ext_vector_type(2)));
+                        v2d_ img[NIT];
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const int e = it * 64 + lane;
+                            img[it] = *reinterpret_cast<const v2d_ *>(Og + 2 * (((it + 1) * 64 <= NPAIR || e < NPAIR) ? e : 0));
+                        }
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const int e = it * 64 + lane;
+                            if ((it + 1) * 64 <= NPAIR || e < NPAIR) *reinterpret_cast<v2d_ *>(o + 2 * e) = img[it];
+                        }
+                        if (((MS * MS) & 1) && lane == 0) o[MS * MS - 1] = Og[MS * MS - 1];
+                    }
+                }
                 }
                 PA_TICK(7 + 2 * (gi & 1));
             }
-            if (C::CORNER_VALU && want_image && !(a.ablate & 128u) && l < C::NCORNER * (C::NCORNER + 1) / 2) {
+            if (C::CORNER_VALU && want_image && !EARLY_OUT && !(a.ablate & 128u) && l < C::NCORNER * (C::NCORNER + 1) / 2) {
                 if (DIRECT) {
                     if (valid) {
                         double *o = a.lc + (cell - a.first) * (size_t)(MS * MS);
@@ -1840,6 +1955,8 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 if (C::USE_PRE) { rec_deposit(); wave_sync(); }      // the next cell's record, into its place in region P
             } else if (DIRECT) {
                 wave_sync();      // the next cell's tables overwrite Z
+            } else if (EARLY_OUT) {
+                wave_sync();      // the next cell's tables overwrite the images
             } else {
                 if (a.lc != nullptr && !(a.ablate & 128u)) {
                     wave_sync();
