@@ -114,6 +114,14 @@
 #ifndef PA_EARLY_OUT
 #define PA_EARLY_OUT 0
 #endif
+// condensed mode: the elimination chain in registers with DPP broadcasts of the pivot row (see hho_local_ops_kernel, S9)
+#ifndef PA_COND_DPP
+#define PA_COND_DPP 1
+#endif
+// condensed mode: region P outside the image of S9 (more LDS, the record deposit where the other modes have it)
+#ifndef PA_COND_OWN_P
+#define PA_COND_OWN_P 1
+#endif
 // blocks of one XCD (blockIdx mod 8) take consecutive cells
 #ifndef PA_XCD_MAP
 #define PA_XCD_MAP 1
@@ -295,7 +303,10 @@ struct Cfg {
     static constexpr int NSP = NF * (NF + 1) / 2, NCOND = NSP + NF;
     static constexpr int oSTG = CBS * LDI >= NCOND ? 0 : (MS + 1) * LDI;
     static constexpr int condNeed = (MS + 1) * LDI + (CBS * LDI >= NCOND ? 0 : NCOND);
-    static constexpr int sizeQ = imax(imax(endQ, ZS * MS), MS * MS);
+    // (condensed mode with COND_OWN_P: the image of S9 lies over region Q only, region P keeps its place behind it and
+    // takes the next cell's record as soon as S6 is done, as in the other modes)
+    static constexpr bool COND_OWN_P = COND && PA_COND_OWN_P && USE_PRE;
+    static constexpr int sizeQ = imax(imax(imax(endQ, ZS * MS), MS * MS), COND_OWN_P ? ((condNeed + 1) & ~1) : 0);
     // region P: lives until the forward substitutions are done.  Stiffness, stride LD; its [1:,1:]
     // block becomes chol(gr_lhs) row by row: oST is odd so that the block (and every row of it)
     // starts on a 16-byte boundary
@@ -791,6 +802,37 @@ __device__ __forceinline__ void dpp_backward(const double (&lr)[NLR], double (&x
     x[K] *= dpp_bcast_e<NLR, NL + K>(lr);
     dpp_backward_row<N, NLR, K, 0>(lr, x);
     if constexpr (K > 0) dpp_backward<N, NLR, K - 1>(lr, x);
+}
+
+// ---- condensed mode: the first NPV steps of the row-by-row Cholesky factorization of the image with the rows in registers
+// (hho_local_ops_kernel, S9).  Step J: s = M[i][J] - sum_{k<J} L[i][k] L[J][k] with L[J][k] = register rA[k] of lane J of the
+// row of 16 lanes (DPP), d = s of lane J, L[i][J] = s / sqrt(d).  rA[J - 1] and s were just written by the vector ALU: the
+// s_nop ties give their DPP reads the two wait states they need.
+template <int NPV, bool TWO, int J, int K>
+__device__ __forceinline__ void cond_dpp_dot(double (&sA)[2], double (&sB)[2], const double (&rA)[NPV], const double (&rB)[TWO ? NPV : 1])
+{
+    if constexpr (K < J) {                                 // (two partial sums per row: the FMAs of a sum are a dependent chain)
+        dpp_fnma<J>(sA[K & 1], rA[K], rA[K]);
+        if (TWO) dpp_fnma<J>(sB[K & 1], rA[K], rB[K]);
+        cond_dpp_dot<NPV, TWO, J, K + 1>(sA, sB, rA, rB);
+    }
+}
+template <int NPV, bool TWO, int J = 0>
+__device__ __forceinline__ void cond_dpp_chain(double (&rA)[NPV], double (&rB)[TWO ? NPV : 1], double &rdiag, int &bad, int q)
+{
+    double pA[2] = {rA[J], 0.0}, pB[2] = {TWO ? rB[J] : 0.0, 0.0};
+    if (J > 0) asm volatile("s_nop 1" : "+v"(rA[J > 0 ? J - 1 : 0]));
+    cond_dpp_dot<NPV, TWO, J, 0>(pA, pB, rA, rB);
+    double sA = J > 1 ? pA[0] + pA[1] : pA[0];
+    const double sB = J > 1 ? pB[0] + pB[1] : pB[0];
+    asm volatile("s_nop 1" : "+v"(sA));
+    const double d = dpp_bcast<J>(sA);
+    if (!(d > 0.0) && !bad) bad = J + 1;
+    const double r = fast_rsqrt<1>(d);
+    rA[J] = sA * r;
+    if (TWO) rB[J] = sB * r;
+    if (q == J) rdiag = r;
+    if constexpr (J + 1 < NPV) cond_dpp_chain<NPV, TWO, J + 1>(rA, rB, rdiag, bad, q);
 }
 
 template <int N, int LD>
@@ -1660,7 +1702,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 cornerU = cornerT * su * su;
             }
         }
-        if (C::USE_PRE && !COND) rec_deposit();
+        if (C::USE_PRE && (!COND || C::COND_OWN_P)) rec_deposit();
         // condensed mode: the cell's right-hand side (lanes < CBS) and, for the recovery, its face unknowns (lanes < NF),
         // one value per lane, in flight during the product
         double fT_l = 0.0, uF_l = 0.0;
@@ -1855,7 +1897,38 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 }
                 if (NPV & 1) row[NPV - 1] = A[i * LDI + NPV - 1];
                 int badc = 0;
-                if (PA_COND_NB > 1) {
+                constexpr bool COND_DPP = PA_COND_DPP && NPV <= 16 && MS + 1 <= 32 && G <= 32;
+                if (COND_DPP) {
+                    // The chain in registers: lane q of each row of 16 lanes holds image rows q and q + 16 (both rows of 16 lanes
+                    // of a 32-lane group hold the same pairs), so every pivot row -- there are at most 16 -- sits in lane j of the
+                    // row of 16 and its prefix reaches the other lanes through the DPP operand of the FMAs (row_newbcast:j):
+                    // no LDS read of the pivot row, no broadcast of the pivot by v_readlane, no LDS write and wait per step.
+                    if (!(a.ablate & 256u)) {
+                    constexpr bool TWO = MS + 1 > 16;
+                    const int q = lane & 15;
+                    const int iA = q <= MS ? q : 0, iB = (TWO && q + 16 <= MS) ? q + 16 : 0;
+                    double rA[NPV], rB[TWO ? NPV : 1], rdiag = 0.0;
+#pragma unroll
+                    for (int k = 0; k + 1 < NPV; k += 2) {
+                        const double2 va = lds_pair(A + iA * LDI + k);
+                        rA[k] = va.x; rA[k + 1] = va.y;
+                        if (TWO) { const double2 vb = lds_pair(A + iB * LDI + k); rB[k] = vb.x; rB[k + 1] = vb.y; }
+                    }
+                    if (NPV & 1) { rA[NPV - 1] = A[iA * LDI + NPV - 1]; if (TWO) rB[NPV - 1] = A[iB * LDI + NPV - 1]; }
+                    cond_dpp_chain<NPV, TWO>(rA, rB, rdiag, badc, q);
+                    // back to the image (the diagonal holds 1 / L[j][j]); one row of 16 lanes writes
+                    if ((G == 16 || l < 16)) {
+#pragma unroll
+                        for (int k = 0; k < NPV; ++k) {
+                            if (q <= MS) A[iA * LDI + k] = (k == q) ? rdiag : rA[k];
+                            if (TWO && q + 16 <= MS) A[iB * LDI + k] = rB[k];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NPV; ++k) row[k] = (TWO && l >= 16) ? rB[TWO ? k : 0] : rA[k];
+                    wave_sync();
+                    }
+                } else if (PA_COND_NB > 1) {
                     if (!(a.ablate & 256u)) badc = lds_partial_cholesky<NPV, MS + 1, PA_COND_NB, LDI>(A, l, row);
                 } else if (!(a.ablate & 256u)) {
 #pragma unroll
@@ -1952,7 +2025,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                     if (valid && a.uT != nullptr && l < CBS) a.uT[(cell - a.first) * (size_t)CBS + l] = t;
                 }
                 wave_sync();      // every read of the image is done
-                if (C::USE_PRE) { rec_deposit(); wave_sync(); }      // the next cell's record, into its place in region P
+                if (C::USE_PRE && !C::COND_OWN_P) { rec_deposit(); wave_sync(); }      // the next cell's record, into its place in region P
             } else if (DIRECT) {
                 wave_sync();      // the next cell's tables overwrite Z
             } else if (EARLY_OUT) {
