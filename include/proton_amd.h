@@ -92,8 +92,10 @@ int pa_context_synchronize(pa_context *ctx);
  * room: next to the persistent local-operator grid of a 512^2 mesh it measured 8 % slower than the plain sequence.) */
 int pa_context_set_cut_overlap(pa_context *ctx, int on);
 const char *pa_last_error(pa_context *ctx);      /* text of the last HIP failure, "" if none  */
-/* The record buffer of the local-operator calls (see pa_local_ops_batch) grows on demand up to a cap -- 4 GiB unless
- * pa_context_set_record_cap says otherwise (>= 1 MiB; larger ranges of cells run in equal pieces) -- and stays with the
+/* The record buffer of the local-operator calls (see pa_local_ops_batch) grows on demand up to a cap -- 4 GiB, or what
+ * pa_context_set_record_cap says (>= 1 MiB; larger ranges of cells run in equal pieces); calls that write local matrices
+ * run in pieces of at most 192 Ki cells anyway (135 MB of records at k = 2: a piece's records stay in the Infinity Cache
+ * between its two kernels) -- and stays with the
  * context for reuse.  pa_context_trim waits for the context's stream and gives it back to the device. */
 int pa_context_set_record_cap(pa_context *ctx, size_t bytes);
 int pa_context_trim(pa_context *ctx);

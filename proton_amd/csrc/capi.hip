@@ -68,6 +68,10 @@ hipError_t conjugated_gradient(hipStream_t stream, size_t n, const int64_t *rowp
                                size_t max_iter, int precond, int *exit_reason, size_t *iterations, double *relative_residual);   // solver.hip
 }
 
+#ifndef PA_PIECE_CELLS
+#define PA_PIECE_CELLS ((size_t)192 * 1024)
+#endif
+
 struct pa_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -786,9 +790,16 @@ static int run_local_ops(pa_context *ctx, pa_degree_info di, int quad_kind, int 
     // piece into the context's record buffer, then the cooperative kernel over the same cells (same stream).
     size_t piece = n;
     if (e->launch_pre) {
-        size_t cap_bytes = ctx->pre_cap_bytes;                            // default 4 GiB of records: 7 M cells at k = 2, 3.9 M at k = 3
+        size_t cap_bytes = ctx->pre_cap_bytes;                            // (pa_context_set_record_cap; default 4 GiB)
         const size_t per_cell = (size_t)e->pre_doubles * sizeof(double);
         size_t max_cells = (cap_bytes / per_cell) & ~(size_t)4095;
+        // Pieces of at most PA_PIECE_CELLS cells by default: the records of a piece (134 MB at k = 2, 255 MB at k = 3) are then
+        // still in the Infinity Cache when the cooperative kernel reads them, and the next piece's overwrite them there --
+        // measured on 1024 x 1024 cells against one piece: 0.53 -> 0.46 ms at k = 1, 1.35 -> 1.27 ms at k = 2, 2.70 -> 2.44 ms at
+        // k = 3, 11.1 -> 9.8 ms on 2048 x 2048 at k = 3 (tools/slab_timing.py; 96 Ki ... 256 Ki cells per piece within 2 %)
+        // (not in the condensed mode, which writes 720 B per cell instead of 3.9 KB and is not short of HBM bandwidth: there the
+        // extra launches and tails cost 2-8 %)
+        if (!o.cond && max_cells > PA_PIECE_CELLS) max_cells = PA_PIECE_CELLS;
         if (max_cells < 4096) max_cells = 4096;
         if (piece > max_cells) {                                          // equal pieces, whole multiples of 4096 cells
             const size_t npieces = (n + max_cells - 1) / max_cells;

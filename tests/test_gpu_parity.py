@@ -168,7 +168,7 @@ def test_batch_matches_oracle(asm, oracle, cd, fd, kind, stabname):
                                                  (0, 1, "tensor", "fancy"), (2, 2, "tensor", "fancy")])      # the last two: dense fancy form
 def test_pre_pass_in_pieces(asm, oracle, cd, fd, kind, stabname):
     """The split path (one-thread-per-cell pre-pass + cooperative kernel, hho_pre.hpp) runs in pieces when the record
-    buffer is capped (pa_context_set_record_cap; 4 GiB by default, i.e. pieces from 4-7 M cells on): same results piece
+    buffer is capped (pa_context_set_record_cap; 4 GiB by default, and pieces of 192 Ki cells when local matrices are written): same results piece
     by piece, bit for bit, as in one pass, and both match the oracle; pa_context_trim gives the buffer back."""
     import torch
     import proton_amd as pa
