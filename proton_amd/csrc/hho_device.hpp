@@ -134,6 +134,14 @@
 #ifndef PA_COND_SCHUR_MFMA_MIN
 #define PA_COND_SCHUR_MFMA_MIN 12
 #endif
+// the per-cell opaque lane index is masked to its range, so that index arithmetic uses 24-bit multiplies
+#ifndef PA_LANE_RANGE
+#define PA_LANE_RANGE 1
+#endif
+// matrix-pipe product: no select on the operand of lanes beyond the last column of Z (they feed entries that are never stored)
+#ifndef PA_ZCOL_NOSEL
+#define PA_ZCOL_NOSEL 1
+#endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
 #else
@@ -1109,6 +1117,9 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         // of every stage out of the cell loop and the kernel spills.
         int l = l0;
         asm volatile("" : "+v"(l));
+#if PA_LANE_RANGE
+        l &= G - 1;      // tell the compiler the range again: its index products fit 24 bits (v_mul_u32_u24 / v_mad_u32_u24 are full rate)
+#endif
         const bool valid = base + g < a.n;
         const size_t cell = a.first + (valid ? base + g : a.n - 1);
         double fbq[NFQ], ufc[FBS];
@@ -1758,9 +1769,14 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 v4d acc[NPAIRS];
                 const double *Zg = smem + gi * C::LDS_PER_CELL + C::oZ;
                 double *Og = smem + gi * C::LDS_PER_CELL + C::oOUT;
+                // (the accumulators start from the zero operand of each tile's first instruction; on the profiling path that
+                // skips the product they are left undefined -- zeroing them ahead of the branch cost 8 moves per cell)
+                if (a.ablate & 64u) {
 #pragma unroll
-                for (int t = 0; t < NPAIRS; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
-                if (!(a.ablate & 64u)) {
+                    for (int t = 0; t < NPAIRS; ++t) asm volatile("" : "=v"(acc[t]));
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NPAIRS; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         const int k = 4 * ks + kk;
@@ -1770,9 +1786,12 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                             if (UPERM_ON && t == 1 && ks >= C::KS1) { z[t] = 0.0; continue; }
                             const int col = 16 * t + jj;
                             // (decided at compile time wherever the whole tile row / k-step is inside Z)
-                            const bool ok = (4 * ks + 3 < C::ZR || k < C::ZR) && (16 * t + 15 < MS || col < MS);
-                            const double v = Zg[ok ? k + col * ZS : 0];
-                            z[t] = ok ? v : 0.0;
+                            const bool rok = 4 * ks + 3 < C::ZR || k < C::ZR, cok = 16 * t + 15 < MS || col < MS;
+                            const double v = Zg[(rok && cok) ? k + col * ZS : 0];
+                            // A lane beyond the last COLUMN of Z feeds only the rows / columns >= MS of the tiles (D[i][j] takes row i of
+                            // A and column j of B), which are never stored: whatever it read (element 0 of Z) may stay.  A lane beyond the
+                            // last ROW of Z would add to entries that are.
+                            z[t] = (PA_ZCOL_NOSEL ? rok : (rok && cok)) ? v : 0.0;
                         }
                         int t = 0;
 #pragma unroll
@@ -2035,7 +2054,9 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                     wave_sync();
                     if (valid) {
                         // (profiling, bit 1024: every pass of a block writes the same two matrices -- the stores without their HBM traffic)
-                        double *o = a.lc + ((a.ablate & 1024u) ? lblock * C::CPW + g : cell - a.first) * (size_t)(MS * MS);
+                        // (the block's part of the address is wave-uniform: scalar arithmetic; the lane adds its group's matrix)
+                        const size_t cb = (a.ablate & 1024u) ? lblock * C::CPW : base;
+                        double *o = a.lc + cb * (size_t)(MS * MS) + (uint32_t)g * (uint32_t)(MS * MS);
                         constexpr int NPAIR = MS * MS / 2, NIT = cdiv(NPAIR, G);
                         // every read of the image first, then the stores: with a read and its store per step the compiler
                         // reuses one register quad and the steps become a chain of LDS round trips
