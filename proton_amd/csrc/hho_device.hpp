@@ -1039,6 +1039,37 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         }
     }
 
+    // Per-lane index constants of the unit form of U (S4b / S6) and of the corner tile, PACKED one word each: kept across
+    // the cell loop in one register and unpacked per pass (a field extract each) -- recomputed from the opaque lane index
+    // they cost ten to seventeen integer instructions per use and pass, held unpacked a register each for the whole kernel.
+    //   unit word:   bits 0-11 offset of the unit's first phi value in the face-point table (doubles from oPHF),
+    //                bits 12-23 offset of its first U entry in Z (doubles from S; the sink for lanes without a unit), bits 24-25 face
+    //   corner word: bits 0-7 ci, 8-15 cj (ci <= cj: the pair of corner columns of this lane), 16-17 face of column ci
+    constexpr bool UNIT_U = C::HAS_STAB && !C::GENERAL_FANCY && !SPLIT && PA_UNIT_U;
+    constexpr bool UPERM_ON = C::UPERM && UNIT_U && !PA_LC_VALU;
+    constexpr int NU = 4 * CBS, UR = UNIT_U ? cdiv(NU, G) : 1;
+    uint32_t unit_pk[UR];
+#pragma unroll
+    for (int r = 0; r < UR; ++r) {
+        const int u = l0 + r * G;
+        const bool on = u < NU;
+        const int uu = on ? u : 0;
+        const int f = uu / CBS, cc = uu - f * CBS;
+        const int ur = (UPERM_ON ? ((f + 4 - C::UF1) & 3) : f) * FBS;           // row block of face f (see Cfg::UPERM)
+        const int zoff = on ? C::oZ + NRP + ur + cc * ZS : C::oDUMMY;            // (the sink holds 4 doubles)
+        static_assert(!UNIT_U || (NFP * RBS < 4096 && C::oDUMMY < 4096 && ZS * MS < 4096), "packed unit offsets: 12 bits each");
+        unit_pk[r] = (uint32_t)(f * NFQ * RBS + cc) | ((uint32_t)zoff << 12) | ((uint32_t)f << 24);
+    }
+    uint32_t corner_pk = 0;
+    if (C::CORNER_VALU) {
+        int cj_ = 0;
+#pragma unroll
+        for (int j = 1; j < C::NCORNER; ++j) cj_ += l0 >= j * (j + 1) / 2 ? 1 : 0;
+        const int ci_ = l0 - cj_ * (cj_ + 1) / 2;                                // ci_ <= cj_
+        const int cf_ = (l0 < C::NCORNER * (C::NCORNER + 1) / 2) ? (16 + ci_ - CBS) / FBS : 0;
+        corner_pk = (uint32_t)(ci_ & 0xff) | ((uint32_t)cj_ << 8) | ((uint32_t)(cf_ & 3) << 16);
+    }
+
     // pairs of the cell's pre-pass record this lane moves to LDS, and where their two doubles go
     typedef typename C::Pre PRE;
     int pre_dst[C::PLC][2];
@@ -1079,8 +1110,12 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
     const size_t stride = (size_t)gridDim.x * C::CPW;
     auto rec_issue = [&](size_t b) {
         // records lie in tiles of 8 cells, [tile][pair][cell % 8] (hho_pre.hpp): the pairs of one record are 128 bytes apart
-        const size_t i = b + g < a.n ? b + g : a.n - 1;
-        const double *pc = a.pre + (((i >> 3) * (size_t)PRE::NP2) * 8 + (i & 7)) * 2;
+        // (b is a multiple of the CPW cells of a wavefront, CPW divides 8: the wavefront's cells share a tile, whose address is
+        // wave-uniform -- scalar arithmetic; a lane adds its slot.  Past the end the lanes read records of the first tile, or
+        // the unwritten slots of the last one -- the buffer holds whole tiles --, and nothing they compute is stored.)
+        static_assert(8 % C::CPW == 0, "the cells of a wavefront share a record tile");
+        const size_t bu = b < a.n ? b : 0;
+        const double *pc = a.pre + (bu >> 3) * (size_t)(PRE::NP2 * 16) + (((uint32_t)bu & 7u) + (uint32_t)g) * 2u;
 #pragma unroll
         for (int t = 0; t < C::PLC; ++t) {
             const int e2 = l0 + t * G;
@@ -1342,7 +1377,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         const int c = l < MS ? l : 0;
         double col[NR];
 #pragma unroll
-        for (int i = 0; i < NR; ++i) col[i] = 1.0;
+        for (int i = 0; i < NR; ++i) asm volatile("" : "=v"(col[i]));      // (every lane writes every row below; only a profiling build's skipped stage leaves them as they are -- a constant here cost a move per row and pass)
         // Cell columns: stiff[1:, c] minus sum_pf (w dphi.n)[pf][:] phi_c(x_pf).  The NR rows of a column
         // are split over SPC lanes (there are only CBS cell columns for G lanes); the pieces meet in
         // the GRC scratch (on the dead quadrature tables) and the column owner reloads them after
@@ -1538,20 +1573,18 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         // 4 CBS units of FBS entries (trace, L^^-1, scale) instead of every column lane carrying all NF rows of its
         // column through the same steps with CBS of G lanes useful; the face columns of U are -sqrt(|F|/2h) L^^T E_F,
         // constants times the face's scale.  Nothing of U is held in registers across the stages.
-        constexpr bool UNIT_U = C::HAS_STAB && !C::GENERAL_FANCY && !SPLIT && PA_UNIT_U;
-        constexpr bool UPERM_ON = C::UPERM && UNIT_U && !PA_LC_VALU;
-        constexpr int NU = 4 * CBS, UR = UNIT_U ? cdiv(NU, G) : 1;
         double uval[UR][FBS];
         double uph[UR][NFQ], usu[UR];
+        uint32_t upk[UR];
+#pragma unroll
+        for (int r = 0; r < UR; ++r) { upk[r] = unit_pk[r]; asm volatile("" : "+v"(upk[r])); }      // (unpacked per pass, not hoisted)
         if (UNIT_U && !(a.ablate & 32u)) {
 #pragma unroll
             for (int r = 0; r < UR; ++r) {
-                const int u = l + r * G;
-                const int uu = ((r + 1) * G <= NU || u < NU) ? u : 0;
-                const int f = uu / CBS, cc = uu - f * CBS;
+                const double *ph = S + C::oPHF + (upk[r] & 0xfffu);
 #pragma unroll
-                for (int q = 0; q < NFQ; ++q) uph[r][q] = S[C::oPHF + (f * NFQ + q) * RBS + cc];
-                usu[r] = S[C::oSU + f];
+                for (int q = 0; q < NFQ; ++q) uph[r][q] = ph[q * RBS];
+                usu[r] = S[C::oSU + (upk[r] >> 24)];
             }
             // (every read of the units first: one LDS round trip)
 #pragma unroll
@@ -1571,7 +1604,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         PA_TICK(12);
         double ucol[C::HAS_STAB ? NF : 1];
 #pragma unroll
-        for (int r = 0; r < (C::HAS_STAB ? NF : 1); ++r) ucol[r] = 1.0;
+        for (int r = 0; r < (C::HAS_STAB ? NF : 1); ++r) asm volatile("" : "=v"(ucol[r]));
         if (C::HAS_STAB && !UNIT_U && !(a.ablate & 32u)) {
             constexpr int TCOLS = C::GENERAL_FANCY ? RBS : CBS;
             const int m = l < TCOLS ? l : 0;
@@ -1616,12 +1649,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         if (UNIT_U && !(a.ablate & 32u)) {
 #pragma unroll
             for (int r = 0; r < UR; ++r) {
-                const int u = l + r * G;
-                const bool on = (r + 1) * G <= NU || u < NU;          // whole rounds: known at compile time
-                const int uu = on ? u : 0;
-                const int f = uu / CBS, cc = uu - f * CBS;
-                const int ur = (UPERM_ON ? ((f + 4 - C::UF1) & 3) : f) * FBS;           // row block of face f (see Cfg::UPERM)
-                double *zu = S + (on ? C::oZ + NRP + ur + cc * ZS : C::oDUMMY);           // (the sink holds 4 doubles)
+                double *zu = S + ((upk[r] >> 12) & 0xfffu);
 #pragma unroll
                 for (int k = 0; k < FBS; ++k) zu[k] = uval[r][k];
             }
@@ -1705,11 +1733,11 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         double cornerU = 0.0;
         int cic = 0, cjc = 0;
         if (C::CORNER_VALU && !SPLIT && !PA_LC_VALU) {
-#pragma unroll
-            for (int j = 1; j < C::NCORNER; ++j) cjc += l >= j * (j + 1) / 2 ? 1 : 0;
-            cic = l - cjc * (cjc + 1) / 2;                               // cic <= cjc
+            uint32_t cpk = corner_pk;
+            asm volatile("" : "+v"(cpk));
+            cic = (int)(cpk & 0xffu); cjc = (int)((cpk >> 8) & 0xffu);       // cic <= cjc
             if (CORNER_SHORT && l < C::NCORNER * (C::NCORNER + 1) / 2) {
-                const double su = S[C::oSU + (16 + cic - CBS) / FBS];
+                const double su = S[C::oSU + (cpk >> 16)];
                 cornerU = cornerT * su * su;
             }
         }
