@@ -313,6 +313,29 @@ class Pipeline:
             assert bool(torch.isfinite(v).all()) and float(v.abs().max()) > 0.0 and bool(torch.isfinite(self.b).all())
 
 
+def settle(torch, dist, world, fn, seconds):
+    """Untimed passes of the step before the W warmup steps, about `seconds` of them: after idling the GPU runs the first
+    ~20 ms of a burst of work at lower clocks (tools/steps_sweep.sh: the kernels of the headline step take 1.43 ms over the
+    first 5 steps after 3 warmup steps, 1.24-1.30 ms from the 30th on), which with W = 3..5 and K = 20 would be a tenth of
+    the timed region -- and made the HIP-event kernel time disagree with the rocprofv3 average over all launches.  The same
+    number of passes on every rank (the step of several GPUs contains an exchange).  Returns the number of passes."""
+    if seconds <= 0:
+        return 0
+    fn(None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn(None)
+    torch.cuda.synchronize()
+    one = max(time.perf_counter() - t0, 1e-5)
+    n = torch.tensor([min(2000, max(1, int(seconds / one)))])
+    if world > 1:
+        dist.all_reduce(n, op=dist.ReduceOp.MAX)
+    for _ in range(int(n[0])):
+        fn(None)
+    torch.cuda.synchronize()
+    return int(n[0]) + 2
+
+
 def timed(torch, dist, world, fn, steps, warmup, with_index=True):
     for _ in range(warmup):
         fn(None)
@@ -344,6 +367,8 @@ def main():
                     help="nccl = RCCL, one rank per GPU (what the driver runs); gloo = rehearsal of the N>1 code path with "
                          "several ranks sharing the visible GPU(s) and a host-staged exchange (numbers not comparable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--settle-ms", type=float, default=250.0,
+                    help="untimed passes of the step before the warmup steps, in ms of GPU work (clock ramp after idle); 0 = none")
     ap.add_argument("--no-one-gpu-reference", action="store_true", help="N>1: skip the same step on rank 0's GPU alone")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="cell rows timed by the CPU baseline (0 = auto)")
     args = ap.parse_args()
@@ -420,6 +445,7 @@ def main():
             pipe.host_exchange = host_exchange
         dist.barrier()                                     # communicators exist before anything is timed
 
+    n_settle = settle(torch, dist, world, pipe.step, args.settle_ms * 1e-3)
     elapsed = timed(torch, dist, world, pipe.step, args.steps, args.warmup)
     stages = pipe.stage_ms(args.steps)
     kern_ms = stages["ops"]
@@ -431,6 +457,7 @@ def main():
     if world > 1 and not args.no_one_gpu_reference:
         if rank == 0:
             ref = Pipeline(torch, pa, w, mode, (0, N), N, local_rank)
+            settle(torch, dist, 1, ref.step, args.settle_ms * 1e-3)
             t_ref = timed(torch, dist, 1, ref.step, max(3, args.steps // 4), 1)
             one_gpu = {"value": N * N / (t_ref / max(3, args.steps // 4)), "ms_per_step": t_ref / max(3, args.steps // 4) * 1e3}
             del ref
@@ -472,6 +499,8 @@ def main():
             "metric": BASELINE_METRIC,
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
+            "settle": {"passes": n_settle, "ms": args.settle_ms,
+                       "what": "untimed passes of the same step BEFORE the W warmup steps (GPU clock ramp after idle, tools/steps_sweep.sh)"},
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "mode": mode,

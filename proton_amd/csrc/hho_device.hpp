@@ -142,6 +142,15 @@
 #ifndef PA_ZCOL_NOSEL
 #define PA_ZCOL_NOSEL 1
 #endif
+// lc through the LDS image: columns of Z permuted in the tiles so that a lane's accumulators are four consecutive rows (16-byte image writes)
+#ifndef PA_ACC_PERM
+#define PA_ACC_PERM 1
+#endif
+// two column tiles without the vector-pipe corner (msize 25..32): tile (1,1) of Z^T Z holds face columns only -- its U term in closed form,
+// its matrix instructions stop after the rows of Y
+#ifndef PA_T11_SHORT
+#define PA_T11_SHORT 1
+#endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
 #else
@@ -1070,6 +1079,34 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         corner_pk = (uint32_t)(ci_ & 0xff) | ((uint32_t)cj_ << 8) | ((uint32_t)(cf_ & 3) << 16);
     }
 
+    // Tile (1,1) of Z^T Z where it runs on the matrix pipe (msize 25..32, no vector-pipe corner) with T_F = [trace_F | 0]: its columns
+    // are face columns, whose U parts are -sqrt(|F|/2h) L^^T e_k on the rows of their own face, so the U term of an entry is
+    // su_F^2 (L^^ L^^T)[ki][kj] for two columns of one face and nothing otherwise: a constant per accumulator times the face's
+    // scale, added after the products -- which then stop after the rows of Y (k = 3: 4 of 8 k-steps, 20 instead of 24 matrix
+    // instructions per cell).
+    constexpr int NTL_ = (MS + 15) / 16;
+    constexpr bool T11_SHORT = PA_T11_SHORT && UNIT_U && NTL_ == 2 && !C::CORNER_VALU && CBS <= 16 && !PA_LC_VALU && !SPLIT;
+    constexpr bool ACC_PERM_ = PA_ACC_PERM && !(C::DIRECT_STORE && !COND) && !COND && MS % 2 == 0;
+    double t11c[4] = {0.0, 0.0, 0.0, 0.0};
+    int t11f = 0;
+    if (T11_SHORT) {
+        const int kk_ = lane >> 4, jj_ = lane & 15;
+        const int col = 16 + (ACC_PERM_ ? 4 * (jj_ & 3) + (jj_ >> 2) : jj_);
+        if (col < MS) {
+            t11f = (col - CBS) / FBS;
+            const int kc = (col - CBS) % FBS;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 + (ACC_PERM_ ? 4 * kk_ + r : kk_ + 4 * r);
+                if (row < MS && (row - CBS) / FBS == t11f) {
+                    const int kr = (row - CBS) % FBS;
+#pragma unroll
+                    for (int j = 0; j < FBS; ++j) t11c[r] += tab->face[C::FD].lft[j][kr] * tab->face[C::FD].lft[j][kc];
+                }
+            }
+        }
+    }
+
     // pairs of the cell's pre-pass record this lane moves to LDS, and where their two doubles go
     typedef typename C::Pre PRE;
     int pre_dst[C::PLC][2];
@@ -1157,6 +1194,10 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
 #endif
         const bool valid = base + g < a.n;
         const size_t cell = a.first + (valid ? base + g : a.n - 1);
+        // offset of the lane's cell in an output / input array of X doubles per cell: the block's part is wave-uniform (scalar
+        // arithmetic), the lane adds its group's (lanes past the end: the first cell of the pass, which exists)
+        const uint32_t gl = valid ? (uint32_t)g : 0u;
+        auto rel = [&](uint32_t X) -> size_t { return base * (size_t)X + (size_t)(gl * X); };
         double fbq[NFQ], ufc[FBS];
         if (FACE_SEL) {
             const int kfl = (l >= CBS && l < MS) ? (l - CBS) % FBS : 0;
@@ -1637,7 +1678,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             else if (C::USE_PRE) lds_backward_rd<NR, LD>(LG, S + C::oRCP, col);
             else lds_backward<NR, LD>(LG, col);            // col = oper[:, c]
             if (a.oper != nullptr && valid && l < MS) {
-                double *dst = a.oper + (cell - a.first) * (size_t)(NR * MS) + (size_t)c * NR;
+                double *dst = a.oper + rel(NR * MS) + (size_t)c * NR;
 #pragma unroll
                 for (int k = 0; k < NR; ++k) dst[k] = col[k];
             }
@@ -1741,13 +1782,21 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 cornerU = cornerT * su * su;
             }
         }
+        double t11s[T11_SHORT ? C::CPW : 1];      // squared scale of the lane's tile-(1,1) column face, for each cell of the wavefront
+        if (T11_SHORT) {
+#pragma unroll
+            for (int gi = 0; gi < C::CPW; ++gi) {
+                const double su = smem[gi * C::LDS_PER_CELL + C::oSU + t11f];
+                t11s[gi] = su * su;
+            }
+        }
         if (C::USE_PRE && (!COND || C::COND_OWN_P)) rec_deposit();
         // condensed mode: the cell's right-hand side (lanes < CBS) and, for the recovery, its face unknowns (lanes < NF),
         // one value per lane, in flight during the product
         double fT_l = 0.0, uF_l = 0.0;
         if (COND) {
-            if (a.rhs != nullptr && l < CBS) fT_l = a.rhs[(cell - a.first) * (size_t)CBS + l];
-            if (a.uF != nullptr && l < NF) uF_l = a.uF[(cell - a.first) * (size_t)NF + l];
+            if (a.rhs != nullptr && l < CBS) fT_l = a.rhs[rel(CBS) + l];
+            if (a.uF != nullptr && l < NF) uF_l = a.uF[rel(NF) + l];
         }
 
         // ================= S7/S8 (lc only): lc = Z^T Z on the matrix pipe ============
@@ -1767,6 +1816,13 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             constexpr bool DIRECT = C::DIRECT_STORE && !COND;      // condensed mode: always through the LDS image
             constexpr bool EARLY_OUT = PA_EARLY_OUT && !DIRECT && !COND && C::CPW > 1;
             constexpr int OS = COND ? C::LDI : MS;                 // stride of the image
+            // Through the image with an even stride: the columns of Z are fed to the tiles in the order pi(i) = 4 (i & 3) + (i >> 2),
+            // both operands alike, so that the lane's four accumulators D[kk + 4 r][jj] are lc[16 I + 4 kk + r][16 J + pi(jj)], r = 0..3:
+            // FOUR CONSECUTIVE rows of one column of the image -- two 16-byte LDS writes instead of four 8-byte ones, and the 16 lanes
+            // of a write cycle (kk fixed, pi(jj) = all 16 columns) fall on 16 different bank quads where the 8-byte column writes at
+            // stride 22 met two by two.  The mirror copy of an off-diagonal tile stays 8-byte writes.
+            constexpr bool ACC_PERM = PA_ACC_PERM && !DIRECT && !COND && OS % 2 == 0;      // (condensed k = 2: 8 spilled registers with it, and no gain)
+            const int pj = ACC_PERM ? 4 * (jj & 3) + (jj >> 2) : jj;
             const bool want_image = COND || a.lc != nullptr;
             // no barrier is needed between the cells: the wavefront reads a cell's Z and then overwrites
             // it with the same cell's output image in program order
@@ -1812,7 +1868,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
 #pragma unroll
                         for (int t = 0; t < NTL; ++t) {
                             if (UPERM_ON && t == 1 && ks >= C::KS1) { z[t] = 0.0; continue; }
-                            const int col = 16 * t + jj;
+                            const int col = 16 * t + pj;
                             // (decided at compile time wherever the whole tile row / k-step is inside Z)
                             const bool rok = 4 * ks + 3 < C::ZR || k < C::ZR, cok = 16 * t + 15 < MS || col < MS;
                             const double v = Zg[(rok && cok) ? k + col * ZS : 0];
@@ -1821,13 +1877,24 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                             // last ROW of Z would add to entries that are.
                             z[t] = (PA_ZCOL_NOSEL ? rok : (rok && cok)) ? v : 0.0;
                         }
+                        // tile (1,1), short form: rows of Y only (the last of their k-steps may also hold rows of U: masked)
+                        constexpr int KSY = cdiv(NRP, 4);
+                        double z1y = z[NTL - 1];
+                        if (T11_SHORT && ks == KSY - 1 && NRP % 4 != 0) z1y = k < NRP ? z1y : 0.0;
                         int t = 0;
 #pragma unroll
                         for (int I = 0; I < NTL; ++I)
 #pragma unroll
-                            for (int J = I; J < NTL; ++J, ++t)
-                                if (!(C::CORNER_VALU && I == 1 && J == 1) && !(UPERM_ON && J == 1 && ks >= C::KS1))
+                            for (int J = I; J < NTL; ++J, ++t) {
+                                if (T11_SHORT && I == 1 && J == 1) {
+                                    if (ks < KSY) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(z1y, z1y, acc[t], 0, 0, 0);
+                                } else if (!(C::CORNER_VALU && I == 1 && J == 1) && !(UPERM_ON && J == 1 && ks >= C::KS1))
                                     acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[I], z[J], acc[t], 0, 0, 0);
+                            }
+                    }
+                    if (T11_SHORT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[NPAIRS - 1][r] = __builtin_fma(t11c[r], t11s[gi], acc[NPAIRS - 1][r]);
                     }
                 }
                 PA_TICK(6 + 2 * (gi & 1));
@@ -1866,8 +1933,25 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                     for (int I = 0; I < NTL; ++I)
 #pragma unroll
                         for (int J = I; J < NTL; ++J, ++t) {
-                            const int colj = 16 * J + jj;
+                            const int colj = 16 * J + pj;
                             if ((16 * J + 15 < MS || colj < MS) && !(C::CORNER_VALU && I == 1 && J == 1)) {
+                                if (ACC_PERM) {
+                                    const int row0 = 16 * I + 4 * kk;
+                                    typedef double v2d_ __attribute__((ext_vector_type(2)));
+                                    if (16 * I + 15 < MS || row0 + 3 < MS) {
+                                        *reinterpret_cast<v2d_ *>(Og + row0 + colj * OS) = v2d_{acc[t][0], acc[t][1]};
+                                        *reinterpret_cast<v2d_ *>(Og + row0 + 2 + colj * OS) = v2d_{acc[t][2], acc[t][3]};
+                                    } else {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r)
+                                            if (row0 + r < MS) Og[row0 + r + colj * OS] = acc[t][r];
+                                    }
+                                    if (I != J) {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r)
+                                            if (16 * I + 15 < MS || row0 + r < MS) Og[colj + (row0 + r) * OS] = acc[t][r];
+                                    }
+                                } else {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int row = 16 * I + kk + 4 * r;
@@ -1876,6 +1960,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                                         Og[row + colj * OS] = v;
                                         if (I != J) Og[colj + row * OS] = v;
                                     }
+                                }
                                 }
                             }
                         }
@@ -1912,7 +1997,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             if (C::CORNER_VALU && want_image && !EARLY_OUT && !(a.ablate & 128u) && l < C::NCORNER * (C::NCORNER + 1) / 2) {
                 if (DIRECT) {
                     if (valid) {
-                        double *o = a.lc + (cell - a.first) * (size_t)(MS * MS);
+                        double *o = a.lc + rel(MS * MS);
                         o[(16 + cic) + (16 + cjc) * MS] = corner;
                         o[(16 + cjc) + (16 + cic) * MS] = corner;
                     }
@@ -2046,7 +2131,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                     wave_sync();
                     PA_TICK(14);
                     if (valid && a.cond != nullptr) {
-                        double *o = a.cond + (cell - a.first) * (size_t)C::NCOND;
+                        double *o = a.cond + rel(C::NCOND);
                         static_assert(C::NCOND % 2 == 0, "16-byte stores of the packed record");
 #pragma unroll
                         for (int e0 = 0; e0 < C::NCOND / 2; e0 += G) {
@@ -2069,7 +2154,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                         if (l == m) t = um;
                         else if (l < m) t = __builtin_fma(-A[m * LDI + k], um, t);
                     }
-                    if (valid && a.uT != nullptr && l < CBS) a.uT[(cell - a.first) * (size_t)CBS + l] = t;
+                    if (valid && a.uT != nullptr && l < CBS) a.uT[rel(CBS) + l] = t;
                 }
                 wave_sync();      // every read of the image is done
                 if (C::USE_PRE && !C::COND_OWN_P) { rec_deposit(); wave_sync(); }      // the next cell's record, into its place in region P
@@ -2153,7 +2238,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             }
             wave_sync();
             if (valid) {
-                double *o = dst + (cell - a.first) * (size_t)(MS * MS);
+                double *o = dst + rel(MS * MS);
                 constexpr int NPAIR = MS * MS / 2, NIT = cdiv(NPAIR, G);
                 typedef double v2d_ __attribute__((ext_vector_type(2)));
                 v2d_ img[NIT];                             // reads first, then the stores (see the lc-only path)
@@ -2174,7 +2259,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             wave_sync();
         }
         }
-        if (valid && a.info != nullptr && l == 0) a.info[cell - a.first] = bad;
+        if (valid && a.info != nullptr && l == 0) a.info[rel(1)] = bad;
         PA_TICK(10);
     }
 #ifdef PA_STAGE_CLOCK

@@ -5,7 +5,7 @@ W=$1; L=$2; M=${3:-L}
 export TMPDIR=/tmp
 for A in 0 1 4 16 32 64 128; do
   D=gpurun_out/ldsc/${W}_$A; rm -rf $D; mkdir -p $D
-  PA_LIB=$L PA_ABLATE=$A rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $D -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload $W --mode $M > $D/bench.json 2> $D/err.log
+  PA_LIB=$L PA_ABLATE=$A rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $D -o p -- python3 bench.py --settle-ms 0 --steps 3 --warmup 1 --no-cpu-baseline --workload $W --mode $M > $D/bench.json 2> $D/err.log
   python3 - "$D" "$A" <<'PY'
 import csv, glob, sys, collections
 d, a = sys.argv[1], sys.argv[2]

@@ -11,7 +11,7 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_IN
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
          "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D/pass$i -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --workload $W > $D/pass$i.json 2> $D/pass$i.err || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D/pass$i -o p -- python3 bench.py --steps 4 --warmup 1 --settle-ms 0 --no-cpu-baseline --workload $W > $D/pass$i.json 2> $D/pass$i.err || echo "pass $i failed"
   echo "pass $i ($C) done"
 done
 python3 tools/pmc_reduce.py $D $W > $OUT && cat $OUT

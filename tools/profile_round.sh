@@ -21,7 +21,7 @@ for spec in $SPECS; do
   fi
   for C in "${PASSES[@]}"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D/pass$i -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload $W --mode $M > $D/pass$i.json 2> $D/pass$i.err || echo "pmc pass $i failed: $spec"
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D/pass$i -o p -- python3 bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --workload $W --mode $M > $D/pass$i.json 2> $D/pass$i.err || echo "pmc pass $i failed: $spec"
   done
   python3 tools/profile_reduce.py $D $W $M $D/bench.json > $OUT/${TAG}_pmc_${W}_$M.json
   echo "$spec done: $(python3 -c "import json;r=json.load(open('$OUT/${TAG}_pmc_${W}_$M.json'));print('hbm bytes %.3g, alg %.3g, kernel_ms %s'%(r['hbm_bytes_per_launch_dominant_kernel'], r.get('algorithmic_bytes_per_launch',0), r.get('bench_kernel_ms_under_profiler')))")"
