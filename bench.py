@@ -64,6 +64,7 @@ WORKLOADS = {
 BASELINE_METRIC = 'cells assembled/sec (+ achieved HBM GB/s) on N×N quad mesh, k=1..3'
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # 256 CU x 4 SIMD x 16 FMA/clk x 2 x 2.4 GHz; v_mfma_f64_16x16x4_f64 measured at 64 clk = the same rate
+FP64_SUSTAINED_TFLOPS = 62.7  # measured on the box (tools/probe/valu_rate.hip): a wave64 v_fma_f64 every 2.09 ns per SIMD = 1.91 GHz sustained
 
 
 def reference_flops_per_cell(w):
@@ -528,6 +529,8 @@ def main():
                 "bound": "fp64", "achieved": n_local * fl / (kern_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": n_local * fl / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                 "reference_flops_per_cell": fl,
+                "peak_sustained_measured": FP64_SUSTAINED_TFLOPS,
+                "frac_of_sustained": n_local * fl / (kern_ms * 1e-3) / 1e12 / FP64_SUSTAINED_TFLOPS,
                 "source": "exact count of the instrumented CPU restatement (oracle/flopcount -> oracle/flops_per_cell.json)"},
             "stage_ms": stage_max,
             "kernel_only_cells_per_s": n_local * world / (kern_ms * 1e-3),

@@ -151,6 +151,11 @@
 #ifndef PA_T11_SHORT
 #define PA_T11_SHORT 1
 #endif
+// condensed mode: number of pivots from which the elimination chain runs in its right-looking form (see cond_dpp_chain_rl;
+// measured: -2.5 % at the 15 pivots of k = 3, +-0.5 % at the 10 of k = 2 and the 6 of k = 1)
+#ifndef PA_COND_RL_MIN
+#define PA_COND_RL_MIN 12
+#endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
 #else
@@ -850,6 +855,38 @@ __device__ __forceinline__ void cond_dpp_chain(double (&rA)[NPV], double (&rB)[T
     if (TWO) rB[J] = sB * r;
     if (q == J) rdiag = r;
     if constexpr (J + 1 < NPV) cond_dpp_chain<NPV, TWO, J + 1>(rA, rB, rdiag, bad, q);
+}
+
+// The same chain RIGHT-looking: once column J is final (s / sqrt(d)), every later column takes its term at once,
+//   M[i][K] -= L[i][J] L[K][J],  K = J+1 .. NPV-1   (L[K][J] = register rA[J] of lane K of the row of 16: DPP),
+// independent FMAs, so that a step's dependent path is pivot broadcast -> rsqrt -> scale -> ONE FMA into the next pivot
+// column, where the left-looking form has the J-term dot product in front of the rsqrt.  Each entry still receives its
+// terms in ascending J (the order of the row-by-row LLT).
+template <int NPV, bool TWO, int J, int K>
+__device__ __forceinline__ void cond_dpp_update(double (&rA)[NPV], double (&rB)[TWO ? NPV : 1])
+{
+    if constexpr (K < NPV) {
+        dpp_fnma<K>(rA[K], rA[J], rA[J]);
+        if (TWO) dpp_fnma<K>(rB[K], rA[J], rB[J]);
+        cond_dpp_update<NPV, TWO, J, K + 1>(rA, rB);
+    }
+}
+template <int NPV, bool TWO, int J = 0>
+__device__ __forceinline__ void cond_dpp_chain_rl(double (&rA)[NPV], double (&rB)[TWO ? NPV : 1], double &rdiag, int &bad, int q)
+{
+    double sA = rA[J];
+    asm volatile("s_nop 1" : "+v"(sA));                    // (written by the previous step's FMA: wait states of its DPP read)
+    const double d = dpp_bcast<J>(sA);
+    if (!(d > 0.0) && !bad) bad = J + 1;
+    const double r = fast_rsqrt<1>(d);
+    rA[J] = sA * r;
+    if (TWO) rB[J] = rB[J] * r;
+    if (q == J) rdiag = r;
+    if constexpr (J + 1 < NPV) {
+        asm volatile("s_nop 1" : "+v"(rA[J]));
+        cond_dpp_update<NPV, TWO, J, J + 1>(rA, rB);
+        cond_dpp_chain_rl<NPV, TWO, J + 1>(rA, rB, rdiag, bad, q);
+    }
 }
 
 template <int N, int LD>
@@ -2047,7 +2084,8 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                         if (TWO) { const double2 vb = lds_pair(A + iB * LDI + k); rB[k] = vb.x; rB[k + 1] = vb.y; }
                     }
                     if (NPV & 1) { rA[NPV - 1] = A[iA * LDI + NPV - 1]; if (TWO) rB[NPV - 1] = A[iB * LDI + NPV - 1]; }
-                    cond_dpp_chain<NPV, TWO>(rA, rB, rdiag, badc, q);
+                    if (NPV >= PA_COND_RL_MIN) cond_dpp_chain_rl<NPV, TWO>(rA, rB, rdiag, badc, q);
+                    else cond_dpp_chain<NPV, TWO>(rA, rB, rdiag, badc, q);
                     // back to the image (the diagonal holds 1 / L[j][j]); one row of 16 lanes writes
                     if ((G == 16 || l < 16)) {
 #pragma unroll

@@ -43,6 +43,21 @@ if len(sys.argv) > 4:
         out["algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes_per_cell"] * b["roofline"]["cells_per_launch"]
     except Exception as e:      # noqa: BLE001
         out["bench_line_error"] = str(e)
+# rocprofv3 --kernel-trace --stats of the same command: the dominant kernels' time PER STEP = calls x average / steps (a step
+# launches them once per piece of <= 192 Ki cells); steps under the profiler = settle passes + warmup + timed steps
+if len(sys.argv) > 5 and os.path.exists(sys.argv[5]) and "bench_line_error" not in out and len(sys.argv) > 4:
+    try:
+        b = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+        nsteps = b["steps"] + b["warmup"] + (b.get("settle") or {}).get("passes", 0)
+        per = {}
+        for r in csv.DictReader(open(sys.argv[5])):
+            if "hho_local_ops_kernel" in r["Name"] or "hho_cell_pre_kernel" in r["Name"]:
+                per[r["Name"][:110]] = {"calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]),
+                                        "ms_per_step": int(r["Calls"]) * float(r["AverageNs"]) / nsteps * 1e-6}
+        out["rocprof_kernel_stats"] = {"steps_under_profiler": nsteps, "kernels": per,
+                                       "dominant_kernel_ms_per_step": sum(v["ms_per_step"] for v in per.values())}
+    except Exception as e:      # noqa: BLE001
+        out["rocprof_kernel_stats_error"] = str(e)
 out["notes"] = ("separate rocprofv3 --pmc passes with --kernel-trace only; FETCH_SIZE / WRITE_SIZE in KiB; FETCH doubled per "
                 "MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B); SQ_* cycle counters in quad-cycles except "
                 "SQ_LDS_IDX_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES")

@@ -23,9 +23,12 @@ for spec in $SPECS; do
     i=$((i+1))
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D/pass$i -o p -- python3 bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --workload $W --mode $M > $D/pass$i.json 2> $D/pass$i.err || echo "pmc pass $i failed: $spec"
   done
-  python3 tools/profile_reduce.py $D $W $M $D/bench.json > $OUT/${TAG}_pmc_${W}_$M.json
-  echo "$spec done: $(python3 -c "import json;r=json.load(open('$OUT/${TAG}_pmc_${W}_$M.json'));print('hbm bytes %.3g, alg %.3g, kernel_ms %s'%(r['hbm_bytes_per_launch_dominant_kernel'], r.get('algorithmic_bytes_per_launch',0), r.get('bench_kernel_ms_under_profiler')))")"
+  python3 tools/profile_reduce.py $D $W $M $D/bench.json $OUT/${TAG}_kstats_${W}_$M.csv > $OUT/${TAG}_pmc_${W}_$M.json
+  cp $D/bench.json $OUT/${TAG}_bench_under_rocprof_${W}_$M.json
+  echo "$spec done: $(python3 -c "import json;r=json.load(open('$OUT/${TAG}_pmc_${W}_$M.json'));print('hbm bytes %.3g, alg %.3g, kernel_ms events %s rocprof %s'%(r['hbm_bytes_per_launch_dominant_kernel'], r.get('algorithmic_bytes_per_launch',0), r.get('bench_kernel_ms_under_profiler'), (r.get('rocprof_kernel_stats') or {}).get('dominant_kernel_ms_per_step')))")"
 done
+if [ -z "$PA_PROFILE_NO_AUX" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/aux -o p -- python3 tools/profile_aux.py > $OUT/aux.log 2>&1 || echo "aux run failed"
 cp $(find $OUT/aux -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kstats_aux.csv 2>/dev/null
+fi
 echo "profile_round done"
