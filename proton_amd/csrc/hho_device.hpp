@@ -156,6 +156,16 @@
 #ifndef PA_COND_RL_MIN
 #define PA_COND_RL_MIN 12
 #endif
+// 8-byte LDS reads of the product's operands and of the unit form of U kept single (volatile): no ds_read2_b64
+#ifndef PA_LDS_NOPAIR
+#define PA_LDS_NOPAIR 0
+#endif
+// S1 with the pre-pass: TWO lanes per face point -- one forms its row of scaled monomials, the other its row of weighted normal
+// derivatives -- and ONE common run of LDS stores (a store instruction costs its 6 ... 13 cycles of the store path whatever the
+// number of active lanes: 5 instead of 10 of them per pass at k = 2)
+#ifndef PA_S1_SPLIT
+#define PA_S1_SPLIT 1
+#endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
 #else
@@ -434,6 +444,14 @@ __device__ __forceinline__ double fast_sqrt(double x)
 // keeps the order, not s_barrier -- and not what __syncthreads() adds to it, a wait for every outstanding global
 // store (vmcnt(0)): with it each cell ended with the wavefront idle until HBM had acknowledged its local matrix.
 __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// 8-byte LDS read that the compiler may not pair with a neighbour into ds_read2_b64 (volatile, in the LDS address space: a volatile
+// access through a generic pointer would become a flat load)
+__device__ __forceinline__ double lds_single(const double *p)
+{
+    typedef const volatile __attribute__((address_space(3))) double *lds_cvp;
+    return *(lds_cvp)p;
+}
 
 // 16-byte LDS read of two consecutive doubles (p is 16-byte aligned by construction of the LDS map)
 __device__ __forceinline__ double2 lds_pair(const double *p) { return *reinterpret_cast<const double2 *>(p); }
@@ -981,6 +999,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
 #pragma unroll
         for (int k = 0; k <= i; ++k) ft.lf[i][k] = to_sgpr(tab->face[C::FD].lf[i][k]);
 
+    constexpr bool S1_SPLIT = PA_S1_SPLIT && C::USE_PRE && 2 * NFP <= G && C::PPL == 1;
     // ---- per-lane, cell-invariant bookkeeping -------------------------------------------
     // reference coordinates of the evaluation points this lane owns
     double r0[C::PPL], r1[C::PPL], r2[C::PPL], rw[C::PPL];
@@ -1002,8 +1021,8 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 r2[r] = tab->dun[R][row][2];
                 rw[r] = tab->dun[R][row][3];
             }
-        } else if (p < NP) {
-            const int q = (p - C::NQB) % NFQ;
+        } else if (p < NP || (S1_SPLIT && p < 2 * NFP)) {
+            const int q = (S1_SPLIT && p >= NFP ? p - NFP : p - C::NQB) % NFQ;
             r0[r] = tab->gauss_x[NFQ][q];
             rw[r] = 0.5 * tab->gauss_w[NFQ][q];
         }
@@ -1308,6 +1327,58 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         PA_TICK(0);
         // ================= S1: evaluation points ======================================
         PA_MARK("S1");
+        if (S1_SPLIT) {
+            // face points only (the cell points belong to the pre-pass): lane p < NFP forms phi at point p, lane NFP + p the
+            // weighted normal derivatives there; both rows leave through the same store instructions
+            if (!(a.ablate & 1u) && l < 2 * NFP) {
+                const bool dnrow = l >= NFP;
+                const int pf = dnrow ? l - NFP : l;
+                const int f = pf / NFQ;
+                const double *sc = S + C::oSU;
+                const double2 pa_ = lds_pair(sc + 8 + 2 * f), pb_ = lds_pair(sc + 8 + 2 * ((f + 1) & 3));
+                const bool descending = (((int)sc[16]) >> f) & 1;                  // the face's first vertex has the higher point id
+                const double wnx = rw[0] * (pb_.y - pa_.y), wny = -rw[0] * (pb_.x - pa_.x);      // (w_q |F|/2) n: the edge length cancels
+                const double t = descending ? -r0[0] : r0[0];                      // bases.hpp:260-261
+                const double x = 0.5 * (1 - t) * pa_.x + 0.5 * (1 + t) * pb_.x;    // quadratures.hpp:420-428
+                const double y = 0.5 * (1 - t) * pa_.y + 0.5 * (1 + t) * pb_.y;
+                const double bx_ = (x - barx) * ih, by_ = (y - bary) * ih;
+                double pwx[RD + 1], pwy[RD + 1];
+                pwx[0] = 1.0; pwy[0] = 1.0;
+#pragma unroll
+                for (int e = 1; e <= RD; ++e) { pwx[e] = pwx[e - 1] * bx_; pwy[e] = pwy[e - 1] * by_; }
+                double out[RBS];
+                // (an empty volatile asm in each arm: a real branch on the execution mask -- if-converted, the arms' results meet in two
+                // selects per double)
+                if (!dnrow) {
+                    asm volatile("");
+                    int m = 0;
+#pragma unroll
+                    for (int kk = 0; kk <= RD; ++kk)
+#pragma unroll
+                        for (int ii = 0; ii <= kk; ++ii, ++m) out[m] = pwx[kk - ii] * pwy[ii];      // (px,py) = (k-i, i)  bases.hpp:119-120
+                } else {
+                    asm volatile("");
+                    const double gnx = ih * wnx, gny = ih * wny;
+                    int m = 0;
+#pragma unroll
+                    for (int kk = 0; kk <= RD; ++kk)
+#pragma unroll
+                        for (int ii = 0; ii <= kk; ++ii, ++m) {
+                            const int ex_ = kk - ii, ey_ = ii;
+                            if (m > 0) {
+                                const double gx = ex_ == 0 ? 0.0 : (ex_ * gnx) * pwx[ex_ > 0 ? ex_ - 1 : 0] * pwy[ey_];
+                                const double gy = ey_ == 0 ? 0.0 : (ey_ * gny) * pwx[ex_] * pwy[ey_ > 0 ? ey_ - 1 : 0];
+                                out[m - 1] = gx + gy;
+                            }
+                        }
+                    out[RBS - 1] = 0.0;
+                }
+                double *dst = S + (dnrow ? C::oDN + pf * NRP : C::oPHF + pf * RBS);
+#pragma unroll
+                for (int m = 0; m < RBS; ++m)
+                    if (m < NR || !dnrow) dst[m] = out[m];
+            }
+        } else
         if (!(a.ablate & 1u)) {   // S1
 #pragma unroll
         for (int r = 0; r < C::PPL; ++r) {
@@ -1661,7 +1732,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             for (int r = 0; r < UR; ++r) {
                 const double *ph = S + C::oPHF + (upk[r] & 0xfffu);
 #pragma unroll
-                for (int q = 0; q < NFQ; ++q) uph[r][q] = ph[q * RBS];
+                for (int q = 0; q < NFQ; ++q) uph[r][q] = PA_LDS_NOPAIR ? lds_single(ph + q * RBS) : ph[q * RBS];
                 usu[r] = S[C::oSU + (upk[r] >> 24)];
             }
             // (every read of the units first: one LDS round trip)
@@ -1908,7 +1979,9 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                             const int col = 16 * t + pj;
                             // (decided at compile time wherever the whole tile row / k-step is inside Z)
                             const bool rok = 4 * ks + 3 < C::ZR || k < C::ZR, cok = 16 * t + 15 < MS || col < MS;
-                            const double v = Zg[(rok && cok) ? k + col * ZS : 0];
+                            // (a volatile read stays ONE ds_read_b64 -- 64 banks, two groups of 32 lanes, 2 cycles --; the compiler otherwise pairs the
+                            // reads of two k-steps into ds_read2_b64: 32 banks, groups of 16 lanes, 8 cycles, and columns j, j + 8 on one bank at this stride)
+                            const double v = PA_LDS_NOPAIR ? lds_single(Zg + ((rok && cok) ? k + col * ZS : 0)) : Zg[(rok && cok) ? k + col * ZS : 0];
                             // A lane beyond the last COLUMN of Z feeds only the rows / columns >= MS of the tiles (D[i][j] takes row i of
                             // A and column j of B), which are never stored: whatever it read (element 0 of Z) may stay.  A lane beyond the
                             // last ROW of Z would add to entries that are.

@@ -61,3 +61,40 @@ def test_dpp_operands_have_no_valu_write_hazard():
         results = list(ex.map(lint.one, [c for c, _ in BASELINE_INSTANCES]))
     assert sum(n for n, _ in results) > 0                     # the instances do use the DPP form
     assert not [b for _, bad in results for b in bad], [b for _, bad in results for b in bad][:5]
+
+
+# (instance, mangled-name key of its lc-only kernel, budget of the cell loop: vector instructions, matrix instructions, LDS instructions)
+LOOP_BUDGETS = [
+    ((2, 1, 0, 16), "CfgILi2ELi1ELi0ELi2ELi16ELi0EEELi0E", 220, 16, 58),      # measured at the end of round 2: 200 / 16 / 50
+    ((3, 2, 0, 32), "CfgILi3ELi2ELi0ELi2ELi32ELi0EEELi0E", 405, 20, 116),     # 372 / 20 / 105
+    ((4, 3, 0, 32), "CfgILi4ELi3ELi0ELi2ELi32ELi0EEELi0E", 660, 40, 165),     # 604 / 40 / 150
+]
+
+
+def test_cell_loop_of_the_headline_kernels_stays_within_its_instruction_budget():
+    """The cooperative kernel answers to its instruction count (half of the vector instructions of a pass were
+    index arithmetic, moves and selects before they were removed), and part of that count is in the compiler's hands: the
+    per-pass opaque lane index, the profiling branches that keep per-lane values from being hoisted, the packed per-lane index
+    words.  A census of the generated ISA of the cell loop (tools/isa_stages.py on a -DPA_MARKERS listing, static counts over
+    both arms of the profiling branches) must stay within ~10 % of what was measured; the matrix instructions exactly."""
+    spec = importlib.util.spec_from_file_location("pa_isa_stages", os.path.join(ROOT, "tools", "isa_stages.py"))
+    isa = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(isa)
+    import tempfile
+
+    def one(job):
+        (cd, fd, q, gmin), key, _, _, _ = job
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "k.s")
+            isa.build_listing(cd, fd, q, gmin, path)
+            cnt, res = isa.census(path, key)
+        return isa.loop_totals(cnt), res
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=3) as ex:
+        results = list(ex.map(one, LOOP_BUDGETS))
+    for (cfg, key, vmax, mfma, ldsmax), (tot, res) in zip(LOOP_BUDGETS, results):
+        assert res.get("scratch") == 0, (cfg, res)
+        assert tot["scratch"] == 0, (cfg, dict(tot))
+        assert tot["mfma"] == mfma, (cfg, dict(tot))
+        assert tot["valu64"] + tot["valu"] <= vmax, (cfg, dict(tot))
+        assert tot["lds"] <= ldsmax, (cfg, dict(tot))
