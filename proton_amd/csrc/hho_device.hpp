@@ -1931,6 +1931,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             // stride 22 met two by two.  The mirror copy of an off-diagonal tile stays 8-byte writes.
             constexpr bool ACC_PERM = PA_ACC_PERM && !DIRECT && !COND && OS % 2 == 0;      // (condensed k = 2: 8 spilled registers with it, and no gain)
             const int pj = ACC_PERM ? 4 * (jj & 3) + (jj >> 2) : jj;
+            static_assert(!T11_SHORT || ACC_PERM == ACC_PERM_, "the per-lane constants of tile (1,1) assume this tile's lane -> (row, column) map");
             const bool want_image = COND || a.lc != nullptr;
             // no barrier is needed between the cells: the wavefront reads a cell's Z and then overwrites
             // it with the same cell's output image in program order
