@@ -208,6 +208,7 @@ class Pipeline:
         self.sz = pa.sizes_for(self.di, self.quad)
         self.asm = BatchAssembler(device_index)
         self.comm, self.host_exchange = comm, host_exchange
+        self._side = self._pin_out = self._pin_in = self._ev_pack = None
         asm, sz, dev = self.asm, self.sz, self.asm.device
         self.cut = bool(w.get("cut"))
         if self.cut:
@@ -287,11 +288,33 @@ class Pipeline:
                                           None if self.halo_in is None else self.halo_in.data_ptr(),
                                           0 if self.halo_in is None else self.halo_in.numel())
         elif self.host_exchange is not None:
-            self.host_exchange(self.halo_out if ci.halo_cells else None, self.halo_in)
+            # host-staged transport (rehearsal, or RCCL did not come up): like the RCCL path the exchange runs NEXT TO the
+            # kernels of the other rows -- the packed rows are complete at this event; the copies and the gloo messages
+            # happen in _exchange_wait, on a side stream, after the rest of the step's kernels have been launched
+            self._ev_pack = self.torch.cuda.Event()
+            self._ev_pack.record()
 
     def _exchange_wait(self):
+        torch = self.torch
         if self.comm is not None:
             self.comm.wait()
+        elif self.host_exchange is not None:
+            ci = self.ci
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+                self._pin_out = torch.empty(self.halo_out.shape, dtype=self.halo_out.dtype).pin_memory() if ci.halo_cells else None
+                self._pin_in = None if self.halo_in is None else torch.empty(self.halo_in.shape, dtype=self.halo_in.dtype).pin_memory()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._ev_pack)
+                if self._pin_out is not None:
+                    self._pin_out.copy_(self.halo_out, non_blocking=True)
+                self._side.synchronize()
+                self.host_exchange.exchange_host(self._pin_out, self._pin_in)
+                if self._pin_in is not None and self.host_exchange.rank > 0:
+                    self.halo_in.copy_(self._pin_in, non_blocking=True)
+                ev_in = torch.cuda.Event()
+                ev_in.record(self._side)
+            torch.cuda.current_stream().wait_event(ev_in)
 
     def stage_ms(self, steps):
         """mean HIP-event time between the ticks of a step, per stage name"""
@@ -368,6 +391,8 @@ def main():
                     help="nccl = RCCL, one rank per GPU (what the driver runs); gloo = rehearsal of the N>1 code path with "
                          "several ranks sharing the visible GPU(s) and a host-staged exchange (numbers not comparable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rccl-timeout", type=float, default=180.0,
+                    help="N>1: seconds to wait for the RCCL communicator before the step falls back to the host-staged exchange")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="untimed passes of the step before the warmup steps, in ms of GPU work (clock ramp after idle); 0 = none")
     ap.add_argument("--no-one-gpu-reference", action="store_true", help="N>1: skip the same step on rank 0's GPU alone")
@@ -403,6 +428,7 @@ def main():
     comm = None
     host_exchange = None
     rccl_error = None
+    abandoned_thread = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # torch.distributed carries the bootstrap (RCCL unique id), the barriers and the max over ranks of the timings;
@@ -421,10 +447,24 @@ def main():
                 ids, rccl_error = [None], repr(e)
             dist.broadcast_object_list(ids, src=0)
             if ids[0] is not None:
-                try:
-                    comm = pa.capi.Comm(pipe.asm.ctx, world, rank, ids[0])
-                except Exception as e:   # noqa: BLE001
-                    rccl_error = repr(e)
+                # ncclCommInitRank is collective and blocks: under a watchdog, so that a rendezvous that never completes
+                # (interface selection, a rank that died) ends in the labelled host-staged transport, not in a hung bench
+                import threading
+                box = {}
+
+                def create():
+                    try:
+                        box["comm"] = pa.capi.Comm(pipe.asm.ctx, world, rank, ids[0])
+                    except Exception as e:   # noqa: BLE001
+                        box["err"] = repr(e)
+                th = threading.Thread(target=create, daemon=True)
+                th.start()
+                th.join(args.rccl_timeout)
+                if th.is_alive():
+                    rccl_error = "RCCL communicator creation did not return within %g s" % args.rccl_timeout
+                    abandoned_thread = True
+                else:
+                    comm, rccl_error = box.get("comm"), box.get("err")
             else:
                 rccl_error = rccl_error or "rank 0 could not create an RCCL unique id"
             # every rank must take the same transport: if RCCL did not come up on ALL of them the step's exchange goes
@@ -455,14 +495,27 @@ def main():
     # N > 1: the same step, same mode, same code, whole mesh, on rank 0's GPU alone (the other ranks wait): the
     # like-for-like one-GPU number of this run
     one_gpu = None
+    exchange_checked = None
     if world > 1 and not args.no_one_gpu_reference:
+        ref_sums = None
         if rank == 0:
             ref = Pipeline(torch, pa, w, mode, (0, N), N, local_rank)
             settle(torch, dist, 1, ref.step, args.settle_ms * 1e-3)
             t_ref = timed(torch, dist, 1, ref.step, max(3, args.steps // 4), 1)
             one_gpu = {"value": N * N / (t_ref / max(3, args.steps // 4)), "ms_per_step": t_ref / max(3, args.steps // 4) * 1e3}
+            if mode == "C":
+                ref_sums = [float(ref.values.sum()), float(ref.values.abs().sum()), float(ref.b.sum()), float(ref.b.abs().sum())]
             del ref
         dist.barrier()
+        if mode == "C":
+            # the slabs' systems stacked are the whole-mesh system: the sums of the CSR values and of the right-hand side over
+            # the ranks must be those of the one-GPU reference -- they are not if a slab's halo rows did not arrive
+            loc = torch.tensor([float(pipe.values.sum()), float(pipe.values.abs().sum()), float(pipe.b.sum()), float(pipe.b.abs().sum())],
+                               dtype=torch.float64)
+            dist.all_reduce(loc, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                exchange_checked = all(abs(a - r) <= 1e-9 * max(abs(ref_sums[1 if i < 2 else 3]), 1e-300) for i, (a, r) in enumerate(zip(loc.tolist(), ref_sums)))
+                assert exchange_checked, ("the ranks' systems do not add up to the whole-mesh system", loc.tolist(), ref_sums)
 
     t = torch.tensor([elapsed, kern_ms] + [stages.get(k, 0.0) for k in ("rhs", "exchange_wait", "fill")], dtype=torch.float64)
     if world > 1:
@@ -536,6 +589,7 @@ def main():
             "kernel_only_cells_per_s": n_local * world / (kern_ms * 1e-3),
             "same_step_one_gpu": None if one_gpu is None else dict(one_gpu, unit="cells/s", speedup=value / one_gpu["value"],
                                                                    what="the identical step (mode %s, whole mesh) on rank 0's GPU alone" % mode),
+            "exchange_checked": exchange_checked,      # N > 1: sums of the ranks' CSR values / right-hand sides == the one-GPU reference's
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline_cut(w) if pipe.cut else cpu_baseline(w, args.cpu_sample_rows)
@@ -547,6 +601,10 @@ def main():
     if comm is not None:
         comm.close()
     if world > 1:
+        dist.barrier()
+        if abandoned_thread:          # a thread is still inside RCCL: leave without running its teardown
+            sys.stdout.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -35,6 +35,16 @@ class HostStagedHalo:
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
 
+    def exchange_host(self, send_host, recv_host):
+        """the same exchange on HOST tensors (pinned staging buffers of a caller that overlaps its device copies itself)"""
+        reqs = []
+        if recv_host is not None and self.rank > 0:
+            reqs.append(dist.irecv(recv_host, src=self.rank - 1))
+        if send_host is not None and self.rank + 1 < self.world:
+            reqs.append(dist.isend(send_host, dst=self.rank + 1))
+        for r in reqs:
+            r.wait()
+
     def __call__(self, send_up, recv_below):
         reqs, staged = [], None
         if recv_below is not None and self.rank > 0:

@@ -6,5 +6,5 @@ python - <<'PY'
 import json
 d = json.loads(open("gpurun_out/rehearse_n2.json").read())
 print("n_gpus", d["n_gpus"], d["config"]["workload"], d["config"]["mode"], "step %.3f ms" % d["ms_per_step"], "settle", d["settle"]["passes"], "exchange:", d["config"]["exchange"][:90])
-print("same_step_one_gpu", d["same_step_one_gpu"])
+print("same_step_one_gpu", d["same_step_one_gpu"], "exchange_checked", d.get("exchange_checked"), "stage_ms", d["stage_ms"])
 PY
