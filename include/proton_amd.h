@@ -480,6 +480,43 @@ int pa_comm_allgather_start(pa_comm *comm, const void *d_send, void *d_recv, siz
 /* in-place sum over the ranks (the dot products of a distributed solve) */
 int pa_comm_allreduce_sum_start(pa_comm *comm, double *d_buf, size_t count);
 int pa_comm_wait(pa_comm *comm);
+/* both neighbours at once (the halo of a vector in a row-partitioned solve): my first n_send_lo doubles to rank - 1, my last
+ * n_send_hi to rank + 1; rank - 1's message into d_recv_lo, rank + 1's into d_recv_hi.  Counts of a missing neighbour are
+ * ignored. */
+int pa_comm_neighbour_exchange_start(pa_comm *comm, const double *d_send_lo, size_t n_send_lo, const double *d_send_hi, size_t n_send_hi,
+                                     double *d_recv_lo, size_t n_recv_lo, double *d_recv_hi, size_t n_recv_hi);
+
+/* ---- the reference's conjugated_gradient on a ROW-PARTITIONED system -------------------------------------------
+ * (solver_cg.hpp:45-144 has one process; this is the solve of the face-only condensed system where it was assembled:
+ * every rank holds the CSR rows [row_begin, row_end) it owns, pa_condensed_csr_fill, with GLOBAL column indices.)
+ * Same recurrences and exit tests in the same order as pa_conjugated_gradient; the dot products are local partial sums
+ * added over the ranks, the search direction's entries a rank's rows read beyond its own range -- the matrix is symmetric
+ * and banded by the mesh's row structure, so they belong to ranks r - 1 and r + 1 -- are refreshed once per iteration.
+ * The transport is three callbacks; NULL = one rank (then the call equals pa_conjugated_gradient, bit for bit).
+ *   allreduce_sum:    sum of n host doubles over the ranks, in place, the same bits on every rank;
+ *   halo:             one neighbour exchange of device ranges (pa_comm_neighbour_exchange_start's arguments; complete or
+ *                     ordered on `stream` when it returns);
+ *   neighbour_counts: at setup, tell the neighbours how many of their entries this rank reads (need_lo below, need_hi
+ *                     above) and learn how many of this rank's first / last entries they read (give_lo, give_hi).
+ * Callbacks return 0 on success.  d_b, d_x: the rank's own rows (row_end - row_begin doubles); x starts from zero.
+ * *transport_status: 0 ok, 1 a callback failed, 2 the rows read beyond what the neighbours can give (or without a
+ * transport beyond the own range). */
+typedef struct {
+    void *user;
+    int (*allreduce_sum)(void *user, double *vals, int n);
+    int (*halo)(void *user, const double *d_send_lo, size_t n_send_lo, const double *d_send_hi, size_t n_send_hi,
+                double *d_recv_lo, size_t n_recv_lo, double *d_recv_hi, size_t n_recv_hi, void *stream);
+    int (*neighbour_counts)(void *user, int64_t need_lo, int64_t need_hi, int64_t *give_lo, int64_t *give_hi);
+} pa_cg_transport;
+int pa_conjugated_gradient_rows(pa_context *ctx, const pa_cg_transport *transport, int64_t row_begin, int64_t row_end,
+                                const int64_t *d_rowptr, const int32_t *d_colind, const double *d_values, const double *d_b, double *d_x,
+                                double convergence_threshold, double divergence_threshold, size_t max_iter, int apply_preconditioner,
+                                int32_t *exit_reason, size_t *iterations, double *relative_residual, int32_t *transport_status);
+/* plain copies ordered on the context's stream and complete on return (what a host-staged transport needs) */
+int pa_copy_to_host(pa_context *ctx, void *host_dst, const void *d_src, size_t bytes);
+int pa_copy_to_device(pa_context *ctx, void *d_dst, const void *host_src, size_t bytes);
+/* the RCCL transport of a communicator (user = the communicator) */
+int pa_comm_cg_transport(pa_comm *comm, pa_cg_transport *out);
 
 /* occupancy / launch facts of the dominant kernel for the roofline bookkeeping */
 typedef struct {

@@ -38,7 +38,19 @@ EXPORTS = [
     "pa_condensed_expand_solution", "pa_condensed_launch_info", "pa_condensed_partition_info",
     "pa_comm_unique_id", "pa_comm_create", "pa_comm_destroy", "pa_comm_info", "pa_comm_last_error",
     "pa_comm_halo_exchange_start", "pa_comm_allgather_start", "pa_comm_allreduce_sum_start", "pa_comm_wait",
+    "pa_comm_neighbour_exchange_start", "pa_conjugated_gradient_rows", "pa_comm_cg_transport", "pa_copy_to_host", "pa_copy_to_device",
 ]
+
+
+# pa_cg_transport: the three callbacks of pa_conjugated_gradient_rows
+CG_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+CG_HALO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                      C.c_void_p)
+CG_COUNTS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+
+
+class CgTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("allreduce_sum", CG_ALLREDUCE), ("halo", CG_HALO), ("neighbour_counts", CG_COUNTS)]
 
 
 class DegreeInfo(C.Structure):
@@ -145,6 +157,12 @@ def lib():
     L.pa_csr_from_triplets.argtypes = [vp, sz, dp, dp, dp, sz, dp, dp, dp, C.POINTER(sz)]
     L.pa_conjugated_gradient.argtypes = [vp, sz, dp, dp, dp, dp, dp, C.c_double, C.c_double, sz, C.c_int,
                                          C.POINTER(C.c_int32), C.POINTER(sz), C.POINTER(C.c_double)]
+    L.pa_conjugated_gradient_rows.argtypes = [vp, C.POINTER(CgTransport), C.c_int64, C.c_int64, dp, dp, dp, dp, dp, C.c_double, C.c_double, sz,
+                                              C.c_int, C.POINTER(C.c_int32), C.POINTER(sz), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.pa_comm_cg_transport.argtypes = [vp, C.POINTER(CgTransport)]
+    L.pa_copy_to_host.argtypes = [vp, vp, vp, sz]
+    L.pa_copy_to_device.argtypes = [vp, vp, vp, sz]
+    L.pa_comm_neighbour_exchange_start.argtypes = [vp, dp, sz, dp, sz, dp, sz, dp, sz]
     L.pa_take_local_data_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp]
     L.pa_project_function_batch.argtypes = [vp, DegreeInfo, C.c_int, C.c_int, C.c_int, dp, dp, sz, sz, dp, dp]
     L.pa_energy_form_batch.argtypes = [vp, DegreeInfo, sz, dp, dp, dp, dp]
@@ -253,6 +271,16 @@ class Comm:
 
     def wait(self):
         self._ck(self._L.pa_comm_wait(self.h), "pa_comm_wait")
+
+    def neighbour_exchange_start(self, send_lo, n_send_lo, send_hi, n_send_hi, recv_lo, n_recv_lo, recv_hi, n_recv_hi):
+        self._ck(self._L.pa_comm_neighbour_exchange_start(self.h, send_lo, n_send_lo, send_hi, n_send_hi, recv_lo, n_recv_lo, recv_hi, n_recv_hi),
+                 "pa_comm_neighbour_exchange_start")
+
+    def cg_transport(self):
+        """the RCCL transport of pa_conjugated_gradient_rows over this communicator"""
+        t = CgTransport()
+        self._ck(self._L.pa_comm_cg_transport(self.h, C.byref(t)), "pa_comm_cg_transport")
+        return t
 
     def close(self):
         if self.h:
@@ -380,6 +408,22 @@ class Context:
         reason, iters, rr = C.c_int32(0), C.c_size_t(0), C.c_double(0.0)
         self._ck(self._L.pa_conjugated_gradient(self.h, nrows, rowptr, colind, values, b, x, tol, div, max_iter, int(precond),
                                                 C.byref(reason), C.byref(iters), C.byref(rr)), "pa_conjugated_gradient")
+        return reason.value, iters.value, rr.value
+
+    def copy_to_host(self, host_dst, d_src, nbytes):
+        self._ck(self._L.pa_copy_to_host(self.h, host_dst, d_src, nbytes), "pa_copy_to_host")
+
+    def copy_to_device(self, d_dst, host_src, nbytes):
+        self._ck(self._L.pa_copy_to_device(self.h, d_dst, host_src, nbytes), "pa_copy_to_device")
+
+    def conjugated_gradient_rows(self, transport, row_begin, row_end, rowptr, colind, values, b, x, tol=1e-9, div=100.0, max_iter=1000,
+                                 precond=True):
+        """pa_conjugated_gradient_rows; transport: a CgTransport (or None = one rank).  Returns (reason, iterations, rr)."""
+        reason, iters, rr, tstat = C.c_int32(0), C.c_size_t(0), C.c_double(0.0), C.c_int32(0)
+        tp = C.byref(transport) if transport is not None else None
+        self._ck(self._L.pa_conjugated_gradient_rows(self.h, tp, row_begin, row_end, rowptr, colind, values, b, x, tol, div, max_iter,
+                                                     int(precond), C.byref(reason), C.byref(iters), C.byref(rr), C.byref(tstat)),
+                 "pa_conjugated_gradient_rows (transport status %d)" % tstat.value)
         return reason.value, iters.value, rr.value
 
     def take_local_data(self, di, first, n, solution, g, out):

@@ -66,6 +66,17 @@ namespace pa {
 hipError_t conjugated_gradient(hipStream_t stream, size_t n, const int64_t *rowptr, const int32_t *colind, const double *values,
                                const double *b, double *x, double convergence_threshold, double divergence_threshold,
                                size_t max_iter, int precond, int *exit_reason, size_t *iterations, double *relative_residual);   // solver.hip
+struct CgTransport {
+    void *user;
+    int (*allreduce_sum)(void *user, double *vals, int n);
+    int (*halo)(void *user, const double *send_lo, size_t n_send_lo, const double *send_hi, size_t n_send_hi, double *recv_lo,
+                size_t n_recv_lo, double *recv_hi, size_t n_recv_hi, void *stream);
+    int (*neighbour_counts)(void *user, int64_t need_lo, int64_t need_hi, int64_t *give_lo, int64_t *give_hi);
+};
+hipError_t conjugated_gradient_rows(hipStream_t stream, const CgTransport *tp, int64_t row_begin, int64_t row_end, const int64_t *rowptr,
+                                    const int32_t *colind, const double *values, const double *b, double *x,
+                                    double convergence_threshold, double divergence_threshold, size_t max_iter, int precond,
+                                    int *exit_reason, size_t *iterations, double *relative_residual, int *transport_status);   // solver.hip
 }
 
 #ifndef PA_PIECE_CELLS
@@ -695,6 +706,44 @@ int pa_conjugated_gradient(pa_context *ctx, size_t nrows, const int64_t *d_rowpt
     PA_HIP(ctx, pa::conjugated_gradient(ctx->stream, nrows, d_rowptr, d_colind, d_values, d_b, d_x, convergence_threshold,
                                         divergence_threshold, max_iter, apply_preconditioner, &reason, iterations, relative_residual));
     if (exit_reason) *exit_reason = reason;
+    return PA_OK;
+}
+
+int pa_conjugated_gradient_rows(pa_context *ctx, const pa_cg_transport *transport, int64_t row_begin, int64_t row_end,
+                                const int64_t *d_rowptr, const int32_t *d_colind, const double *d_values, const double *d_b, double *d_x,
+                                double convergence_threshold, double divergence_threshold, size_t max_iter, int apply_preconditioner,
+                                int32_t *exit_reason, size_t *iterations, double *relative_residual, int32_t *transport_status)
+{
+    if (!ctx || !d_rowptr || row_end < row_begin) return PA_ERR_INVALID_ARG;
+    if (row_end > row_begin && (!d_colind || !d_values || !d_b || !d_x)) return PA_ERR_INVALID_ARG;
+    if (transport && (!transport->allreduce_sum || !transport->halo || !transport->neighbour_counts)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    pa::CgTransport tp{};
+    if (transport) { tp.user = transport->user; tp.allreduce_sum = transport->allreduce_sum; tp.halo = transport->halo; tp.neighbour_counts = transport->neighbour_counts; }
+    int reason = 0, tstat = 0;
+    PA_HIP(ctx, pa::conjugated_gradient_rows(ctx->stream, transport ? &tp : nullptr, row_begin, row_end, d_rowptr, d_colind, d_values, d_b, d_x,
+                                             convergence_threshold, divergence_threshold, max_iter, apply_preconditioner, &reason,
+                                             iterations, relative_residual, &tstat));
+    if (exit_reason) *exit_reason = reason;
+    if (transport_status) *transport_status = tstat;
+    return tstat == 1 ? PA_ERR_COMM : (tstat == 2 ? PA_ERR_INVALID_ARG : PA_OK);
+}
+
+int pa_copy_to_host(pa_context *ctx, void *host_dst, const void *d_src, size_t bytes)
+{
+    if (!ctx || (bytes && (!host_dst || !d_src))) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (bytes) PA_HIP(ctx, hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PA_OK;
+}
+
+int pa_copy_to_device(pa_context *ctx, void *d_dst, const void *host_src, size_t bytes)
+{
+    if (!ctx || (bytes && (!d_dst || !host_src))) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (bytes) PA_HIP(ctx, hipMemcpyAsync(d_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PA_OK;
 }
 

@@ -78,6 +78,7 @@ struct pa_comm {
     hipStream_t side = nullptr;        // the collectives' own stream, so that they overlap kernels enqueued after them
     hipEvent_t ready = nullptr, done = nullptr;
     bool pending = false;
+    double *scratch = nullptr;         // 8 doubles on the device: the scalars of a distributed solve (pa_comm_cg_transport)
     std::string last_error;
 };
 
@@ -146,6 +147,7 @@ int pa_comm_destroy(pa_comm *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->side);
     if (c->comm) (void)rccl()->CommDestroy(c->comm);
+    if (c->scratch) (void)hipFree(c->scratch);
     (void)hipEventDestroy(c->ready); (void)hipEventDestroy(c->done); (void)hipStreamDestroy(c->side);
     delete c;
     return PA_OK;
@@ -190,6 +192,80 @@ int pa_comm_halo_exchange_start(pa_comm *c, const double *d_send_up, size_t send
     if (send) PA_CNCCL(c, r->Send(d_send_up, send_count, ncclFloat64, c->rank + 1, c->comm, c->side));
     PA_CNCCL(c, r->GroupEnd());
     return comm_end(c);
+}
+
+int pa_comm_neighbour_exchange_start(pa_comm *c, const double *d_send_lo, size_t n_send_lo, const double *d_send_hi, size_t n_send_hi,
+                                     double *d_recv_lo, size_t n_recv_lo, double *d_recv_hi, size_t n_recv_hi)
+{
+    if (!c) return PA_ERR_INVALID_ARG;
+    const bool lo = c->rank > 0, hi = c->rank + 1 < c->nranks;
+    const bool s_lo = lo && d_send_lo && n_send_lo, s_hi = hi && d_send_hi && n_send_hi;
+    const bool r_lo = lo && d_recv_lo && n_recv_lo, r_hi = hi && d_recv_hi && n_recv_hi;
+    if (!s_lo && !s_hi && !r_lo && !r_hi) return PA_OK;
+    int st = comm_begin(c);
+    if (st != PA_OK) return st;
+    Rccl *r = rccl();
+    PA_CNCCL(c, r->GroupStart());
+    if (r_lo) PA_CNCCL(c, r->Recv(d_recv_lo, n_recv_lo, ncclFloat64, c->rank - 1, c->comm, c->side));
+    if (r_hi) PA_CNCCL(c, r->Recv(d_recv_hi, n_recv_hi, ncclFloat64, c->rank + 1, c->comm, c->side));
+    if (s_lo) PA_CNCCL(c, r->Send(d_send_lo, n_send_lo, ncclFloat64, c->rank - 1, c->comm, c->side));
+    if (s_hi) PA_CNCCL(c, r->Send(d_send_hi, n_send_hi, ncclFloat64, c->rank + 1, c->comm, c->side));
+    PA_CNCCL(c, r->GroupEnd());
+    return comm_end(c);
+}
+
+// ---- the transport of pa_conjugated_gradient_rows over this communicator (user = the communicator) ----
+static int cgt_scratch(pa_comm *c, double **d)
+{
+    if (!c->scratch) PA_CHIP(c, hipMalloc((void **)&c->scratch, 8 * sizeof(double)));
+    *d = c->scratch;
+    return PA_OK;
+}
+static int cgt_allreduce(void *user, double *vals, int n)
+{
+    pa_comm *c = (pa_comm *)user;
+    if (n > 8) return 1;
+    if (c->nranks == 1) return 0;
+    double *d = nullptr;
+    if (cgt_scratch(c, &d) != PA_OK) return 1;
+    if (hipMemcpyAsync(d, vals, n * sizeof(double), hipMemcpyHostToDevice, c->main) != hipSuccess) return 1;
+    if (pa_comm_allreduce_sum_start(c, d, (size_t)n) != PA_OK || pa_comm_wait(c) != PA_OK) return 1;
+    if (hipMemcpyAsync(vals, d, n * sizeof(double), hipMemcpyDeviceToHost, c->main) != hipSuccess) return 1;
+    return hipStreamSynchronize(c->main) == hipSuccess ? 0 : 1;
+}
+static int cgt_halo(void *user, const double *send_lo, size_t n_send_lo, const double *send_hi, size_t n_send_hi, double *recv_lo,
+                    size_t n_recv_lo, double *recv_hi, size_t n_recv_hi, void *)
+{
+    pa_comm *c = (pa_comm *)user;
+    if (pa_comm_neighbour_exchange_start(c, send_lo, n_send_lo, send_hi, n_send_hi, recv_lo, n_recv_lo, recv_hi, n_recv_hi) != PA_OK) return 1;
+    return pa_comm_wait(c) == PA_OK ? 0 : 1;
+}
+static int cgt_counts(void *user, int64_t need_lo, int64_t need_hi, int64_t *give_lo, int64_t *give_hi)
+{
+    // what I read below is what rank - 1 gives of its LAST entries; what I read above, rank + 1 of its FIRST: the counts
+    // travel as doubles (exact below 2^53) through the neighbour exchange
+    pa_comm *c = (pa_comm *)user;
+    *give_lo = *give_hi = 0;
+    if (c->nranks == 1) return 0;
+    double *d = nullptr;
+    if (cgt_scratch(c, &d) != PA_OK) return 1;
+    double h[4] = {(double)need_lo, (double)need_hi, 0.0, 0.0};
+    if (hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, c->main) != hipSuccess) return 1;
+    if (pa_comm_neighbour_exchange_start(c, d, 1, d + 1, 1, d + 2, 1, d + 3, 1) != PA_OK || pa_comm_wait(c) != PA_OK) return 1;
+    if (hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->main) != hipSuccess) return 1;
+    if (hipStreamSynchronize(c->main) != hipSuccess) return 1;
+    if (c->rank > 0) *give_lo = (int64_t)h[2];                   // rank - 1 sent its need_hi: that many of my first entries
+    if (c->rank + 1 < c->nranks) *give_hi = (int64_t)h[3];       // rank + 1 sent its need_lo: that many of my last entries
+    return 0;
+}
+int pa_comm_cg_transport(pa_comm *c, pa_cg_transport *out)
+{
+    if (!c || !out) return PA_ERR_INVALID_ARG;
+    out->user = c;
+    out->allreduce_sum = cgt_allreduce;
+    out->halo = cgt_halo;
+    out->neighbour_counts = cgt_counts;
+    return PA_OK;
 }
 
 int pa_comm_allgather_start(pa_comm *c, const void *d_send, void *d_recv, size_t bytes_per_rank)

@@ -56,3 +56,82 @@ class HostStagedHalo:
             r.wait()
         if staged is not None:
             recv_below.copy_(staged)
+
+
+class HostStagedCgTransport:
+    """The transport of pa_conjugated_gradient_rows (include/proton_amd.h: pa_cg_transport) on host copies over gloo -- the twin
+    of pa_comm_cg_transport for the tests and the one-GPU rehearsal: ranks in slab order, neighbours r - 1 and r + 1."""
+
+    def __init__(self, rank, world, ctx):
+        from . import capi
+        self.rank, self.world = rank, world
+
+        def allreduce(user, vals, n):
+            try:
+                t = torch.tensor([vals[i] for i in range(n)], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                for i in range(n):
+                    vals[i] = float(t[i])
+                return 0
+            except Exception:       # noqa: BLE001  (a callback must not raise through C)
+                return 1
+
+        def dev_to_host(ptr, n):
+            out = torch.empty(n, dtype=torch.float64)
+            ctx.copy_to_host(out.data_ptr(), ptr, 8 * n)
+            return out
+
+        def host_to_dev(ptr, t):
+            ctx.copy_to_device(ptr, t.data_ptr(), 8 * t.numel())
+
+        def halo(user, send_lo, n_send_lo, send_hi, n_send_hi, recv_lo, n_recv_lo, recv_hi, n_recv_hi, stream):
+            try:
+                ctx.synchronize()
+                reqs, got_lo, got_hi = [], None, None
+                lo, hi = self.rank > 0, self.rank + 1 < self.world
+                if lo and n_recv_lo:
+                    got_lo = torch.empty(n_recv_lo, dtype=torch.float64)
+                    reqs.append(dist.irecv(got_lo, src=self.rank - 1))
+                if hi and n_recv_hi:
+                    got_hi = torch.empty(n_recv_hi, dtype=torch.float64)
+                    reqs.append(dist.irecv(got_hi, src=self.rank + 1))
+                if lo and n_send_lo:
+                    reqs.append(dist.isend(dev_to_host(send_lo, n_send_lo), dst=self.rank - 1))
+                if hi and n_send_hi:
+                    reqs.append(dist.isend(dev_to_host(send_hi, n_send_hi), dst=self.rank + 1))
+                for r in reqs:
+                    r.wait()
+                if got_lo is not None:
+                    host_to_dev(recv_lo, got_lo)
+                if got_hi is not None:
+                    host_to_dev(recv_hi, got_hi)
+                return 0
+            except Exception:       # noqa: BLE001
+                return 1
+
+        def counts(user, need_lo, need_hi, give_lo, give_hi):
+            try:
+                give_lo[0] = 0
+                give_hi[0] = 0
+                reqs, from_lo, from_hi = [], None, None
+                lo, hi = self.rank > 0, self.rank + 1 < self.world
+                if lo:
+                    from_lo = torch.zeros(1, dtype=torch.int64)
+                    reqs.append(dist.irecv(from_lo, src=self.rank - 1))
+                    reqs.append(dist.isend(torch.tensor([need_lo], dtype=torch.int64), dst=self.rank - 1))
+                if hi:
+                    from_hi = torch.zeros(1, dtype=torch.int64)
+                    reqs.append(dist.irecv(from_hi, src=self.rank + 1))
+                    reqs.append(dist.isend(torch.tensor([need_hi], dtype=torch.int64), dst=self.rank + 1))
+                for r in reqs:
+                    r.wait()
+                if lo:
+                    give_lo[0] = int(from_lo[0])      # rank - 1 reads that many of my first entries (its need_hi)
+                if hi:
+                    give_hi[0] = int(from_hi[0])      # rank + 1 reads that many of my last entries (its need_lo)
+                return 0
+            except Exception:       # noqa: BLE001
+                return 1
+
+        self._cbs = (capi.CG_ALLREDUCE(allreduce), capi.CG_HALO(halo), capi.CG_COUNTS(counts))      # keep the thunks alive
+        self.struct = capi.CgTransport(None, *self._cbs)
