@@ -255,7 +255,10 @@ class Pipeline:
             self._tick(i, "start")
             asm.ctx.local_ops(di, self.quad, self.stab, 0, n, None, None, None, self.lc.data_ptr(), None)
             self._tick(i, "ops")
-            asm.ctx.cell_rhs(w["cd"], w["dinc"], self.quad, w["fn"], 0, n, self.rhs.data_ptr(), None)
+            if self.cut:      # the fictitious-domain driver's make_rhs: only the cells of the domain are integrated (cuthho_square.cpp:628-629)
+                asm.ctx.cut_uncut_rhs(w["cd"], pa.capi.LOC_NEGATIVE, w["fn"], self.rhs.data_ptr())
+            else:
+                asm.ctx.cell_rhs(w["cd"], w["dinc"], self.quad, w["fn"], 0, n, self.rhs.data_ptr(), None)
             self._tick(i, "rhs")
             if self.cut and asm.ncut:
                 asm.ctx.cut_merge(w["fd"], pa.capi.LOC_NEGATIVE, self.cut_lc.data_ptr(), self.cut_rhs.data_ptr(), self.lc.data_ptr(),

@@ -406,6 +406,12 @@ int pa_cut_quadrature_points(pa_context *ctx, int face_deg, int where, int which
  * d_bcs_vals at the points of list 2.  d_rhs ncut x cbs. */
 int pa_cut_rhs_sampled_batch(pa_context *ctx, int face_deg, const pa_level_set *ls, int where, const double *d_rhs_vals,
                              const double *d_bcs_vals, double *d_rhs);
+/* make_rhs(msh, cl, degree, where, f) of the fictitious-domain driver for the UNCUT cells (cuthho_square.cpp:623-631, fan
+ * quadrature of degree 2*degree): the cells on the `where` side get utils.hpp:163-171, every other cell -- outside the domain,
+ * or cut: pa_cut_merge puts the cut kernel's right-hand side there -- gets zeros without being integrated (at 512 x 512 with
+ * the circle of radius 0.35 that is 61 % of the cells).  d_rhs: ncells x cbs(degree); the same values pa_cell_rhs_batch
+ * followed by pa_cut_merge's zeroing leaves. */
+int pa_cut_uncut_rhs_batch(pa_context *ctx, int degree, int where, int fn, double *d_rhs);
 /* Merge for the assembly loop of cuthho_square.cpp:883-900: rows of the cut cells in the
  * cell-major d_lc / d_rhs (all cells, from pa_local_ops_batch(PA_QUAD_FAN, PA_STAB_NAIVE) and
  * pa_cell_rhs_batch) are replaced by the cut operators; the right-hand side of uncut cells

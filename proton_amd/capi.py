@@ -38,7 +38,7 @@ EXPORTS = [
     "pa_condensed_expand_solution", "pa_condensed_launch_info", "pa_condensed_partition_info",
     "pa_comm_unique_id", "pa_comm_create", "pa_comm_destroy", "pa_comm_info", "pa_comm_last_error",
     "pa_comm_halo_exchange_start", "pa_comm_allgather_start", "pa_comm_allreduce_sum_start", "pa_comm_wait",
-    "pa_comm_neighbour_exchange_start", "pa_conjugated_gradient_rows", "pa_comm_cg_transport", "pa_copy_to_host", "pa_copy_to_device",
+    "pa_comm_neighbour_exchange_start", "pa_conjugated_gradient_rows", "pa_comm_cg_transport", "pa_copy_to_host", "pa_copy_to_device", "pa_cut_uncut_rhs_batch",
 ]
 
 
@@ -174,6 +174,7 @@ def lib():
     L.pa_cut_query.argtypes = [vp, C.POINTER(sz), vp, vp]
     L.pa_cut_local_ops_batch.argtypes = [vp, C.c_int, C.POINTER(LevelSet), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp]
     L.pa_cut_merge.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp]
+    L.pa_cut_uncut_rhs_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     L.pa_cut_query_tags.argtypes = [vp, vp, vp, vp]
     L.pa_cut_preprocess_agglomeration.argtypes = [vp, sz, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(LevelSet), C.c_int]
     L.pa_cut_agglo_query.argtypes = [vp, vp, vp]
@@ -517,6 +518,9 @@ class Context:
 
     def cut_merge(self, face_deg, where, cut_lc, cut_rhs, lc, rhs):
         self._ck(self._L.pa_cut_merge(self.h, face_deg, where, cut_lc, cut_rhs, lc, rhs), "pa_cut_merge")
+
+    def cut_uncut_rhs(self, degree, where, fn, rhs):
+        self._ck(self._L.pa_cut_uncut_rhs_batch(self.h, degree, where, fn, rhs), "pa_cut_uncut_rhs_batch")
 
     # ---- condensed mode --------------------------------------------------------------
     def condensed_ops(self, di, quad, stab, first, n, rhs, cond, info=None):

@@ -981,14 +981,14 @@ int pa_condensed_launch_info(pa_context *ctx, pa_degree_info di, int quad_kind, 
 // ---- right-hand sides, quadrature points ---------------------------------------------------
 template <int QUAD>
 static int launch_rhs(pa_context *ctx, int degree, int qdeg, int nqp, int fn, const double *d_fvals, size_t first,
-                      size_t n, double *d_rhs)
+                      size_t n, double *d_rhs, const int8_t *d_cell_loc = nullptr, int where = 0)
 {
     const int block = 256;
     const int grid = (int)((n + block - 1) / block);
 #define PA_RHS_CASE(D)                                                                                     \
     case D:                                                                                                \
         hipLaunchKernelGGL((pa::cell_rhs_kernel<D, QUAD>), dim3(grid), dim3(block), 0, ctx->stream, ctx->d_tab, \
-                           ctx->d_points, ctx->d_ptids, first, n, qdeg, nqp, fn, d_fvals, d_rhs);          \
+                           ctx->d_points, ctx->d_ptids, first, n, qdeg, nqp, fn, d_fvals, d_rhs, d_cell_loc, where); \
         break;
     switch (degree) {
         PA_RHS_CASE(0) PA_RHS_CASE(1) PA_RHS_CASE(2) PA_RHS_CASE(3) PA_RHS_CASE(4)
@@ -1597,6 +1597,21 @@ static int cut_local_ops(pa_context *ctx, int face_deg, const pa_level_set *ls, 
     return PA_OK;
 }
 
+int pa_cut_uncut_rhs_batch(pa_context *ctx, int degree, int where, int fn, double *d_rhs)
+{
+    if (!ctx || !d_rhs || degree < 0 || (where != PA_LOC_NEGATIVE && where != PA_LOC_POSITIVE)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (!ctx->cut || !ctx->d_points || !ctx->d_cell_loc) return PA_ERR_NO_MESH;
+    if (fn <= PA_FN_SAMPLED || fn > PA_FN_ONE) return PA_ERR_INVALID_ARG;
+    const int qdeg = 2 * degree;                                   // utils.hpp:165 with di = 0 (cuthho_square.cpp:631)
+    int nqp = 0;
+    const int st = rhs_quadrature(ctx, qdeg, PA_QUAD_FAN, &nqp);
+    if (st != PA_OK) return st;
+    const size_t n = ctx->cut->ncells();
+    if (n == 0) return PA_OK;
+    return launch_rhs<pa::QUAD_FAN>(ctx, degree, qdeg, nqp, fn, nullptr, 0, n, d_rhs, ctx->d_cell_loc, where);
+}
+
 int pa_cut_merge(pa_context *ctx, int face_deg, int where, const double *d_cut_lc, const double *d_cut_rhs, double *d_lc,
                  double *d_rhs)
 {
@@ -1605,13 +1620,19 @@ int pa_cut_merge(pa_context *ctx, int face_deg, int where, const double *d_cut_l
     if (!ctx->cut) return PA_ERR_NO_MESH;
     const int cbs = pa::P2(face_deg + 1), ms = cbs + 4 * (face_deg + 1);
     const uint32_t nc = (uint32_t)ctx->cut->ncells();
-    const int grid = (int)(nc < (uint32_t)ctx->num_cus * 16 ? nc : (uint32_t)ctx->num_cus * 16);
+    const uint32_t ncut = (uint32_t)ctx->cut->cut_cells.size();
     if (ctx->side_pending) {                              // the cut cells' kernel ran on the side stream
         PA_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
         ctx->side_pending = false;
     }
-    hipLaunchKernelGGL(pa::cut_merge_kernel, dim3(grid), dim3(64), 0, ctx->stream, nc, ctx->d_cell_loc, ctx->d_cut_index, where,
-                       ms * ms, cbs, d_cut_lc, d_cut_rhs, d_lc, d_rhs);
+    if (d_rhs != nullptr && nc) {
+        const size_t total = (size_t)nc * (size_t)cbs;
+        hipLaunchKernelGGL(pa::cut_zero_rhs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, total, (uint32_t)cbs,
+                           ctx->d_cell_loc, where, d_rhs);
+    }
+    if (ncut)
+        hipLaunchKernelGGL(pa::cut_merge_cells_kernel, dim3(ncut), dim3(64), 0, ctx->stream, ncut, ctx->d_cut_cells, ms * ms, cbs, d_cut_lc,
+                           d_cut_rhs, d_lc, d_rhs);
     PA_HIP(ctx, hipGetLastError());
     return PA_OK;
 }

@@ -387,22 +387,32 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
 }
 
 // fictitious-domain merge: the cut cells' operators replace the rows of the cell-major arrays and
-// the right-hand side of cells outside `where` is zeroed (cuthho_square.cpp:628-629, 659-664)
-__global__ void cut_merge_kernel(uint32_t ncells, const int8_t *cell_loc, const int32_t *cut_index, int where, int msize2, int cbs,
-                                 const double *cut_lc, const double *cut_rhs, double *lc, double *rhs)
+// the right-hand side of cells outside `where` is zeroed (cuthho_square.cpp:628-629, 659-664).
+// Two launches: one block per CUT cell (the list of cut cells, ~0.5 % of the mesh) copies its matrix and right-hand side;
+// one thread per right-hand-side entry of the whole mesh zeroes those of the cells outside the domain (coalesced stores).
+// (One block per cell of the WHOLE mesh, most of them with nothing or 80 bytes to write, took 51 us of config 3's 620.)
+__global__ __launch_bounds__(64) void cut_merge_cells_kernel(uint32_t ncut, const uint32_t *cut_cells, int msize2, int cbs,
+                                                            const double *cut_lc, const double *cut_rhs, double *lc, double *rhs)
 {
-    for (size_t c = blockIdx.x; c < ncells; c += gridDim.x) {
-        const int loc = cell_loc[c];
-        if (loc == LOC_CUT) {
-            const size_t cc = (size_t)cut_index[c];
-            if (lc != nullptr && cut_lc != nullptr)
-                for (int e = threadIdx.x; e < msize2; e += blockDim.x) lc[c * msize2 + e] = cut_lc[cc * msize2 + e];
-            if (rhs != nullptr && cut_rhs != nullptr)
-                for (int e = threadIdx.x; e < cbs; e += blockDim.x) rhs[c * cbs + e] = cut_rhs[cc * cbs + e];
-        } else if (loc != where && rhs != nullptr) {
-            for (int e = threadIdx.x; e < cbs; e += blockDim.x) rhs[c * cbs + e] = 0.0;
-        }
+    const size_t cc = blockIdx.x;
+    if (cc >= ncut) return;
+    const size_t c = cut_cells[cc];
+    if (lc != nullptr && cut_lc != nullptr) {
+        // (msize^2 is even for the even msize of the cut configurations; the odd tail entry by itself)
+        const double *src = cut_lc + cc * (size_t)msize2;
+        double *dst = lc + c * (size_t)msize2;
+        for (int e = threadIdx.x; e < msize2; e += 64) dst[e] = src[e];
     }
+    if (rhs != nullptr && cut_rhs != nullptr)
+        for (int e = threadIdx.x; e < cbs; e += 64) rhs[c * (size_t)cbs + e] = cut_rhs[cc * (size_t)cbs + e];
+}
+
+__global__ __launch_bounds__(256) void cut_zero_rhs_kernel(size_t total, uint32_t cbs, const int8_t *cell_loc, int where, double *rhs)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int loc = cell_loc[t / cbs];
+    if (loc != LOC_CUT && loc != where) rhs[t] = 0.0;
 }
 
 }  // namespace pa

@@ -159,11 +159,18 @@ template <int DEG, int QUAD>
 __global__ __launch_bounds__(256) void cell_rhs_kernel(const QuadTables *tab, const double *points,
                                                        const uint32_t *ptids, size_t first, size_t n,
                                                        int qdegree, int nqp, int fn, const double *fvals,
-                                                       double *rhs)
+                                                       double *rhs, const int8_t *cell_loc = nullptr, int where = 0)
 {
     constexpr int CBS = P2(DEG);
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    // fictitious domain (cut make_rhs, cuthho_square.cpp:628-629): a cell that is not on the `where` side -- outside the
+    // domain, or cut: its right-hand side comes from the cut kernel -- gets zeros and costs nothing
+    if (cell_loc != nullptr && cell_loc[first + t] != where) {
+#pragma unroll
+        for (int m = 0; m < CBS; ++m) rhs[t * CBS + m] = 0.0;
+        return;
+    }
     CellGeom c;
     load_cell_geom(points, ptids, first + t, c);
     const double ihalf = 1.0 / (0.5 * c.hT);

@@ -336,3 +336,21 @@ def test_config3_at_full_size_cut_cells_merged(asm, oracle):
             assert e < TOL, (int(c), e)
         assert np.abs(rhsh[c] - o_rhs).max() < 1e-12 * max(1.0, np.abs(o_rhs).max())
     assert np.median(errs) < 1e-11, np.median(errs)
+
+
+@pytest.mark.parametrize("N,k", [(20, 1), (24, 2)])
+def test_uncut_rhs_of_the_domain_only_equals_rhs_then_zeroing(asm, N, k):
+    """pa_cut_uncut_rhs_batch (make_rhs of the fictitious-domain driver: cells outside the domain are not integrated,
+    cuthho_square.cpp:628-629) followed by the merge gives, bit for bit, what pa_cell_rhs_batch on every cell followed by
+    the merge's zeroing gives."""
+    import torch
+    import proton_amd as pa
+    asm.cut_preprocess(N, refsteps=4)
+    lc, rhs_ref = asm.fictdom_local_ops(k)
+    cd = k + 1
+    rhs = torch.full_like(rhs_ref, 7.0)
+    asm.ctx.cut_uncut_rhs(cd, pa.capi.LOC_NEGATIVE, pa.capi.FN_SIN_SIN_RHS, rhs.data_ptr())
+    cut = asm.cut_local_ops(k, want=("lc", "rhs"))
+    asm.ctx.cut_merge(k, pa.capi.LOC_NEGATIVE, cut["lc"].data_ptr(), cut["rhs"].data_ptr(), None, rhs.data_ptr())
+    asm.synchronize()
+    assert torch.equal(rhs, rhs_ref)
