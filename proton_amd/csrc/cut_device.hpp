@@ -128,11 +128,17 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
             }
             wave_sync();
             const int nq = (int)((c1 - base) < (uint32_t)CH ? (c1 - base) : (uint32_t)CH);
-            if (l < NMOM)
+            // (unrolled by 8: the LDS reads of eight points are in flight together -- one at a time, each iteration waited for its
+            // own round trip and the kernel's time was the sum of those latencies; the sums keep their order)
+            if (l < NMOM) {
+#pragma unroll 8
                 for (int t = 0; t < nq; ++t) mom_acc += S[oTPHI + t * ROWW + mp] * S[oTPHI + t * ROWW + NPW + mr];
-            if (l < CBS)
+            }
+            if (l < CBS) {
+#pragma unroll 8
                 for (int t = 0; t < nq; ++t)
                     rhs_acc += (S[oTPHI + t * ROWW + rp] * S[oTPHI + t * ROWW + NPW + rr]) * S[oTPHI + t * ROWW + 2 * NPW];
+            }
             wave_sync();
         }
         static_assert(NMOM <= 64, "one lane per moment");
@@ -158,7 +164,8 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                 const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
                 double nx, ny;
                 a.ls.normal(x, y, nx, ny);                    // not flipped for the positive side (:352-355)
-                for (int m = 0; m < RBS; ++m) {
+#pragma unroll
+                for (int m = 0; m < RBS; ++m) {      // (unrolled: the exponents of monomial m are constants, not a search per point)
                     double gx, gy;
                     grad_m(bx, by, m, gx, gy);
                     S[oTPHI + l * RBS + m] = phi_m(bx, by, m);
@@ -171,6 +178,7 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
             for (int e = l; e < RBS * RBS; e += 64) {
                 const int i = e % RBS, j = e / RBS;
                 double s = 0.0;
+#pragma unroll 4
                 for (int t = 0; t < nq; ++t) {
                     const double w = S[oTW + t], pi_ = S[oTPHI + t * RBS + i], pj = S[oTPHI + t * RBS + j];
                     const double di_ = S[oTDN + t * RBS + i], dj = S[oTDN + t * RBS + j];
@@ -199,7 +207,8 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                 const double fbx = 0.5 * (ax + bxx), fby = 0.5 * (ay + byy);
                 const double ep = 4.0 * ((fbx - ax) * (x - fbx) + (fby - ay) * (y - fby)) / (len * len);
                 const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
-                for (int m = 0; m < RBS; ++m) {
+#pragma unroll
+                for (int m = 0; m < RBS; ++m) {      // (unrolled: the exponents of monomial m are constants, not a search per point)
                     double gx, gy;
                     grad_m(bx, by, m, gx, gy);
                     S[oTPHI + l * RBS + m] = phi_m(bx, by, m);
@@ -323,27 +332,34 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
                 }
             }
             wave_sync();
-            // data += oper_F^T mass_F oper_F / hT, oper_F = [ M^-1 trace | -I_F ]  (:599,:615-617); outputs
+            // data += oper_F^T mass_F oper_F / hT, oper_F = [ M^-1 trace | -I_F ]  (:599,:615-617); outputs.
+            // Two tables first, on the dead face-point table: OPF[(f,k)][i] = oper_F (zero rows for a face without points) and
+            // WF[(f,k)][j] = (mass_F oper_F)[k][j]; then every entry is the 4 FBS-term sum  OPF[:, i] . WF[:, j]  over compile-time
+            // rows, its reads in flight together -- the same products in the same order as the nested loops over faces and modes
+            // they replace (which skipped the zero factors one data-dependent branch at a time: 28 of the kernel's 114 us).
+            double *OPF = S + oTPHI, *WF = S + oTPHI + NF * MS;
+            static_assert(2 * NF * MS <= CH * ROWW, "the two tables fit the point table");
+            for (int e = l; e < NF * MS; e += 64) {
+                const int fk = e % NF, i = e / NF, f = fk / FBS, k = fk % FBS;
+                const bool on = a.fs_cnt[cc * 4 + f] != 0;
+                OPF[fk + i * NF] = !on ? 0.0 : (i < CBS ? S[oPT + fk + i * NF] : (i == CBS + fk ? -1.0 : 0.0));
+            }
+            wave_sync();
+            for (int e = l; e < NF * MS; e += 64) {
+                const int fk = e % NF, jc = e / NF, f = fk / FBS, k = fk % FBS;
+                double mo = 0.0;
+#pragma unroll
+                for (int k2 = 0; k2 < FBS; ++k2) mo += S[oMF + f * FBS * FBS + k + k2 * FBS] * OPF[(f * FBS + k2) + jc * NF];
+                WF[fk + jc * NF] = mo;
+            }
+            wave_sync();
             const size_t off = (size_t)cc * (MS * MS);
 #pragma unroll 1
             for (int e = l; e < MS * MS; e += 64) {
-                const int i = e % MS, j = e / MS;
+                const int i = e % MS, jc = e / MS;
                 double s = 0.0;
-#pragma unroll 1
-                for (int f = 0; f < 4; ++f) {
-                    if (a.fs_cnt[cc * 4 + f] == 0) continue;
-#pragma unroll 1
-                    for (int k = 0; k < FBS; ++k) {
-                        const double oi = i < CBS ? S[oPT + (f * FBS + k) + i * NF] : (i == CBS + f * FBS + k ? -1.0 : 0.0);
-                        if (oi == 0.0) continue;
-                        double mo = 0.0;
-                        for (int k2 = 0; k2 < FBS; ++k2) {
-                            const double oj = j < CBS ? S[oPT + (f * FBS + k2) + j * NF] : (j == CBS + f * FBS + k2 ? -1.0 : 0.0);
-                            mo += S[oMF + f * FBS * FBS + k + k2 * FBS] * oj;
-                        }
-                        s += oi * mo;
-                    }
-                }
+#pragma unroll
+                for (int fk = 0; fk < NF; ++fk) s += OPF[fk + i * NF] * WF[fk + jc * NF];
                 const double st = s * (1.0 / hT), dt = S[oDATA + e];
                 if (a.lc != nullptr) a.lc[off + e] = dt + st;
                 if (a.data != nullptr) a.data[off + e] = dt;
@@ -359,25 +375,43 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
             const uint32_t r0 = a.ir_off[cc], r1 = a.ir_off[cc + 1];      // integrate_interface(msh, cl, degree, where)  (:647)
             for (uint32_t base = r0; base < r1; base += CH) {
                 const uint32_t q = base + l;
+                // The point's lane stages the POWERS bx^e, by^e (the products ipow forms, in its order) next to the weighted boundary
+                // value and the normal; the mode's lane then reads the four powers its monomial and its gradient need.  (With
+                // phi_m / grad_m called per point and mode -- exponent search and power loops inside a serial loop over the points --
+                // this stage was 45 of the kernel's 114 us.)
+                constexpr int HROW = 2 * (RD + 1) + 3;
+                static_assert(HROW <= ROWW, "stage H rows fit the point table of stage A");
                 if (q < r1) {
                     const double x = a.ir_xyw[3 * q], y = a.ir_xyw[3 * q + 1];
                     double nx, ny;
                     a.ls.normal(x, y, nx, ny);
-                    S[oTPHI + 5 * l] = (x - barx) * ihalf;
-                    S[oTPHI + 5 * l + 1] = (y - bary) * ihalf;
-                    S[oTPHI + 5 * l + 2] = a.ir_xyw[3 * q + 2] * (a.bcs_fn == FN_SAMPLED ? a.bcs_vals[q] : builtin_fn(a.bcs_fn, x, y));
-                    S[oTPHI + 5 * l + 3] = nx;
-                    S[oTPHI + 5 * l + 4] = ny;
+                    const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
+                    double vx = 1.0, vy = 1.0;
+#pragma unroll
+                    for (int e = 0; e <= RD; ++e) {
+                        S[oTPHI + HROW * l + e] = vx;
+                        S[oTPHI + HROW * l + (RD + 1) + e] = vy;
+                        vx *= bx; vy *= by;
+                    }
+                    S[oTPHI + HROW * l + 2 * (RD + 1)] = a.ir_xyw[3 * q + 2] * (a.bcs_fn == FN_SAMPLED ? a.bcs_vals[q] : builtin_fn(a.bcs_fn, x, y));
+                    S[oTPHI + HROW * l + 2 * (RD + 1) + 1] = nx;
+                    S[oTPHI + HROW * l + 2 * (RD + 1) + 2] = ny;
                 }
                 wave_sync();
                 const int nq = (int)((r1 - base) < (uint32_t)CH ? (r1 - base) : (uint32_t)CH);
-                if (l < CBS)
+                if (l < CBS) {
+                    int hp, hr;
+                    mono_exps(l, hp, hr);
+                    const int hp1 = hp > 0 ? hp - 1 : 0, hr1 = hr > 0 ? hr - 1 : 0;
+                    const double cpx = hp == 0 ? 0.0 : hp * ih, cpy = hr == 0 ? 0.0 : hr * ih;      // (p ih, r ih: the leading factors of grad_m)
+#pragma unroll 4
                     for (int t = 0; t < nq; ++t) {
-                        const double bx = S[oTPHI + 5 * t], by = S[oTPHI + 5 * t + 1];
-                        double gx, gy;
-                        grad_m(bx, by, l, gx, gy);
-                        s += S[oTPHI + 5 * t + 2] * (phi_m(bx, by, l) * eta_h - (gx * S[oTPHI + 5 * t + 3] + gy * S[oTPHI + 5 * t + 4]));
+                        const double *row = S + oTPHI + HROW * t;
+                        const double xp = row[hp], yr = row[(RD + 1) + hr], xp1 = row[hp1], yr1 = row[(RD + 1) + hr1];
+                        const double gx = hp == 0 ? 0.0 : cpx * xp1 * yr, gy = hr == 0 ? 0.0 : cpy * xp * yr1;
+                        s += row[2 * (RD + 1)] * ((xp * yr) * eta_h - (gx * row[2 * (RD + 1) + 1] + gy * row[2 * (RD + 1) + 2]));
                     }
+                }
                 wave_sync();
             }
             if (l < CBS) a.rhs[(size_t)cc * CBS + l] = s;
