@@ -130,14 +130,17 @@ __global__ __launch_bounds__(64, 4) void cut_local_ops_kernel(CutArgs a)
             const int nq = (int)((c1 - base) < (uint32_t)CH ? (c1 - base) : (uint32_t)CH);
             // (unrolled by 8: the LDS reads of eight points are in flight together -- one at a time, each iteration waited for its
             // own round trip and the kernel's time was the sum of those latencies; the sums keep their order)
-            if (l < NMOM) {
+            // (one loop for the moments and the right-hand-side modes: their reads travel together; lanes without a moment / a mode
+            // accumulate into registers nobody reads)
+            {
+                const bool hm = l < NMOM, hr_ = l < CBS;
+                const int mpo = hm ? mp : 0, mro = NPW + (hm ? mr : 0), rpo = hr_ ? rp : 0, rro = NPW + (hr_ ? rr : 0);
 #pragma unroll 8
-                for (int t = 0; t < nq; ++t) mom_acc += S[oTPHI + t * ROWW + mp] * S[oTPHI + t * ROWW + NPW + mr];
-            }
-            if (l < CBS) {
-#pragma unroll 8
-                for (int t = 0; t < nq; ++t)
-                    rhs_acc += (S[oTPHI + t * ROWW + rp] * S[oTPHI + t * ROWW + NPW + rr]) * S[oTPHI + t * ROWW + 2 * NPW];
+                for (int t = 0; t < nq; ++t) {
+                    const double *row = S + oTPHI + t * ROWW;
+                    mom_acc += row[mpo] * row[mro];
+                    rhs_acc += (row[rpo] * row[rro]) * row[2 * NPW];
+                }
             }
             wave_sync();
         }
