@@ -177,9 +177,7 @@ __global__ __launch_bounds__(256) void cell_rhs_kernel(const QuadTables *tab, co
     double acc[CBS];
 #pragma unroll
     for (int m = 0; m < CBS; ++m) acc[m] = 0.0;
-    for (int q = 0; q < nqp; ++q) {
-        double x, y, w;
-        cell_qp<QUAD>(tab, c, qdegree, q, x, y, w);
+    auto point = [&](int q, double x, double y, double w) {
         const double fv = (fn == FN_SAMPLED) ? fvals[t * nqp + q] : builtin_fn(fn, x, y);
         const double bx = (x - c.barx) * ihalf, by = (y - c.bary) * ihalf;
         double pwx[DEG + 1], pwy[DEG + 1];
@@ -191,6 +189,33 @@ __global__ __launch_bounds__(256) void cell_rhs_kernel(const QuadTables *tab, co
         for (int kk = 0; kk <= DEG; ++kk)
 #pragma unroll
             for (int ii = 0; ii <= kk; ++ii, ++m) acc[m] += (w * (pwx[kk - ii] * pwy[ii])) * fv;
+    };
+    if (QUAD == QUAD_TENSOR) {
+        // outer eta, inner xi (quadratures.hpp:355-357): the point order of cell_qp without its division of q per point; the
+        // terms that depend on eta alone are formed once per row
+        const int ng = gauss_nodes(qdegree);
+        int q = 0;
+        for (int j = 0; j < ng; ++j) {
+            const double eta = tab->gauss_x[ng][j], wj = tab->gauss_w[ng][j];
+            for (int i = 0; i < ng; ++i, ++q) {
+                const double xi = tab->gauss_x[ng][i];
+                const double x = 0.25 * c.px[0] * (1 - xi) * (1 - eta) + 0.25 * c.px[1] * (1 + xi) * (1 - eta) +
+                                 0.25 * c.px[2] * (1 + xi) * (1 + eta) + 0.25 * c.px[3] * (1 - xi) * (1 + eta);
+                const double y = 0.25 * c.py[0] * (1 - xi) * (1 - eta) + 0.25 * c.py[1] * (1 + xi) * (1 - eta) +
+                                 0.25 * c.py[2] * (1 + xi) * (1 + eta) + 0.25 * c.py[3] * (1 - xi) * (1 + eta);
+                const double j11 = 0.25 * ((c.px[1] - c.px[0]) * (1 - eta) + (c.px[2] - c.px[3]) * (1 + eta));
+                const double j12 = 0.25 * ((c.py[1] - c.py[0]) * (1 - eta) + (c.py[2] - c.py[3]) * (1 + eta));
+                const double j21 = 0.25 * ((c.px[3] - c.px[0]) * (1 - xi) + (c.px[2] - c.px[1]) * (1 + xi));
+                const double j22 = 0.25 * ((c.py[3] - c.py[0]) * (1 - xi) + (c.py[2] - c.py[1]) * (1 + xi));
+                point(q, x, y, tab->gauss_w[ng][i] * wj * fabs(j11 * j22 - j12 * j21));
+            }
+        }
+    } else {
+        for (int q = 0; q < nqp; ++q) {
+            double x, y, w;
+            cell_qp<QUAD>(tab, c, qdegree, q, x, y, w);
+            point(q, x, y, w);
+        }
     }
 #pragma unroll
     for (int m = 0; m < CBS; ++m) rhs[t * CBS + m] = acc[m];
