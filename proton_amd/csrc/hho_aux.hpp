@@ -211,10 +211,21 @@ __global__ __launch_bounds__(256) void cell_rhs_kernel(const QuadTables *tab, co
             }
         }
     } else {
-        for (int q = 0; q < nqp; ++q) {
-            double x, y, w;
-            cell_qp<QUAD>(tab, c, qdegree, q, x, y, w);
-            point(q, x, y, w);
+        // fan triangles (p_t, p_t+1, barycenter), the Dunavant rows of rules[deg] inside (quadratures.hpp:390-396, 242-268): the
+        // point order of cell_qp with the triangle's edge vectors and area formed once per triangle, not per point
+        const int R = qdegree == 0 ? 1 : qdegree;
+        const int nt = tab->dun_n[R];
+        int q = 0;
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr) {      // (unrolled: the vertices are registers)
+            const int t1 = (tr + 1) & 3;
+            const double ax = c.px[tr], ay = c.py[tr], bx = c.px[t1], by = c.py[t1];
+            const double v0x = bx - ax, v0y = by - ay, v1x = c.barx - ax, v1y = c.bary - ay;
+            const double tarea = fabs((v0x * v1y - v0y * v1x) / 2.0);
+            for (int row = 0; row < nt; ++row, ++q) {
+                const double l0 = tab->dun[R][row][0], l1 = tab->dun[R][row][1], l2 = tab->dun[R][row][2];
+                point(q, ax * l0 + bx * l1 + c.barx * l2, ay * l0 + by * l1 + c.bary * l2, tarea * tab->dun[R][row][3]);
+            }
         }
     }
 #pragma unroll
