@@ -264,7 +264,7 @@ struct Cfg {
     static constexpr int WAVES_LC = PA_WAVES_OVERRIDE;
 #else
     static constexpr int WAVES_LC = PA_WAVES_PER_EU ? PA_WAVES_PER_EU
-                                 : DENSE_FANCY ? ((MS > 24 || RBS > 10) ? 1 : (MS > 16 || RBS > 6) ? 2 : 3)
+                                 : DENSE_FANCY ? ((MS > 24 || RBS > 10) ? 1 : (MS > 16 || RBS > 6) ? 2 : (CBS <= 1 ? 4 : 3))      /* (cell degree 0 -- the obstacle pair (0,1): 120 registers --: 4 against 3 waves: -5 % lc, -17 % condensed; (1,1) spills at 4) */
                                                : ((MS > 24 || RBS > 10) ? 2 : 3);
 #endif
     static constexpr int WAVES = (COND_ != 0 && PA_COND_WAVES_PER_EU) ? PA_COND_WAVES_PER_EU : WAVES_LC;
