@@ -114,6 +114,23 @@ int cut_interface_assemble(const cut_mesh *m, hho_degrees di, size_t cell, const
 /* cell unknowns read back by take_local_data (:1356-1379): offset of the cell block of `where` */
 size_t cut_interface_cell_offset(const cut_mesh *m, hho_degrees di, size_t cell, const int64_t *cell_table, int where);
 
+/* ---- cut_truth.c: the same cut operators in IEEE binary128 (__float128) from the double-valued geometry and
+ * quadrature lists above; the side sliver cells are judged against (cond * eps separates any two double evaluations).
+ * Outputs are rounded to double at the very end.  Cut cells only (HHO_ERR_ARG otherwise). */
+int cut_truth_laplacian(const cut_mesh *m, const cut_level_set *ls, size_t cell, hho_degrees di, int where,
+                        double *oper, double *data);                     /* oper rbs x msize */
+int cut_truth_stabilization(const cut_mesh *m, size_t cell, hho_degrees di, int where, double *stab);
+int cut_truth_rhs(const cut_mesh *m, const cut_level_set *ls, size_t cell, int degree, int where, int f_id, int bcs_id, double *rhs);
+/* data = gr_rhs^T gr_lhs^+ gr_rhs; oper (may be NULL) = the solution with the constant of the negative side pinned to 0 */
+int cut_truth_laplacian_interface(const cut_mesh *m, const cut_level_set *ls, size_t cell, hho_degrees di,
+                                  const cut_params *parms, double *oper, double *data);
+double cut_truth_last_interface_cond(void);   /* 1-norm condition number of the pinned system of the last call above */
+int cut_truth_rhs_side(const cut_mesh *m, size_t cell, int degree, int where, int f_id, double *rhs);
+/* error attribution: 1 = gr_lhs / gr_rhs of cut_truth_laplacian rounded to double once formed (the solve stays binary128) */
+void cut_truth_round_inputs(int on);
+/* 1-norm condition number of the cut cell's rbs x rbs reconstruction system (exact inverse in binary128) */
+double cut_truth_laplacian_cond(const cut_mesh *m, const cut_level_set *ls, size_t cell, hho_degrees di, int where);
+
 #ifdef __cplusplus
 }
 #endif

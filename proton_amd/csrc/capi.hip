@@ -838,7 +838,15 @@ static int run_local_ops(pa_context *ctx, pa_degree_info di, int quad_kind, int 
     // Kernels that take the per-cell head from the pre-pass run in pieces of at most `piece` cells: pre-pass of a
     // piece into the context's record buffer, then the cooperative kernel over the same cells (same stream).
     size_t piece = n;
-    if (e->launch_pre) {
+    if (e->launch_pre && e->self_pre) {
+        // the cooperative kernel forms the records itself: one ring of 64 records per block of the (persistent) grid, one launch
+        const size_t need = (size_t)grid * 64 * (size_t)e->pre_doubles;
+        if (ctx->pre_capacity < need) {
+            if (ctx->d_pre) { PA_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_pre); ctx->d_pre = nullptr; ctx->pre_capacity = 0; }
+            PA_HIP(ctx, hipMalloc((void **)&ctx->d_pre, need * sizeof(double)));
+            ctx->pre_capacity = need;
+        }
+    } else if (e->launch_pre) {
         size_t cap_bytes = ctx->pre_cap_bytes;                            // (pa_context_set_record_cap; default 4 GiB)
         const size_t per_cell = (size_t)e->pre_doubles * sizeof(double);
         size_t max_cells = (cap_bytes / per_cell) & ~(size_t)4095;
@@ -876,7 +884,10 @@ static int run_local_ops(pa_context *ctx, pa_degree_info di, int quad_kind, int 
         a.tab = ctx->d_tab; a.points = ctx->d_points; a.ptids = ctx->d_ptids;
         a.first = first + off; a.n = m;
         a.pre = nullptr;
-        if (e->launch_pre) {
+        a.pre_ring = nullptr;
+        if (e->launch_pre && e->self_pre) {
+            a.pre_ring = ctx->d_pre;
+        } else if (e->launch_pre) {
             pa::PreArgs pa_;
             pa_.tab = ctx->d_tab; pa_.points = ctx->d_points; pa_.ptids = ctx->d_ptids;
             pa_.first = first + off; pa_.n = m; pa_.pre = ctx->d_pre;

@@ -166,6 +166,13 @@
 #ifndef PA_S1_SPLIT
 #define PA_S1_SPLIT 1
 #endif
+// 1: no separate pre-pass kernel and no record array of the whole piece: every 64 / CPW passes a wavefront of the cooperative
+// kernel forms the heads of the 64 cells it visits next itself -- one cell per lane, the thread-per-cell code of hho_pre.hpp -- into a
+// ring of 64 records of its own in global memory (45 KB at k = 2: written and read back by the same compute unit within ~0.2 ms), and
+// reads them from there as before (per instance: proton_amd/_build.py)
+#ifndef PA_SELF_PRE
+#define PA_SELF_PRE 0
+#endif
 #ifdef PA_MARKERS
 #define PA_MARK(x) asm volatile("; PAMARK " x)
 #else
@@ -298,6 +305,9 @@ struct Cfg {
         static constexpr int NP2 = NPRE / 2;                  // 16-byte pairs
     };
     static constexpr int PLC = cdiv(Pre::NP2, G);             // pairs of the record per lane
+    // the wavefront produces the records it consumes (see PA_SELF_PRE): SELF_IT passes per batch of 64 cells
+    static constexpr bool SELF_PRE = USE_PRE && PA_SELF_PRE;
+    static constexpr int SELF_IT = 64 / (64 / G);
 
     // ---- LDS map (doubles, per cell).  Every vector that is read as a contiguous run starts at
     // an even offset and has an even stride, so the reads are 16-byte ds_read_b128.
@@ -379,6 +389,7 @@ struct LocalOpsArgs {
     const uint32_t *ptids;     // nc x 4
     size_t first, n;
     const double *pre;         // records of Cfg::Pre::NPRE doubles (hho_pre.hpp) in tiles of 8 cells; Cfg::USE_PRE only
+    double *pre_ring;          // Cfg::SELF_PRE: gridDim.x rings of 64 records (8 tiles), one per wavefront, written by the kernel itself
     double *oper, *data, *stab, *lc;
     int32_t *info;
     // condensed mode (MODE_COND): f_T per cell (n x cbs, may be null = 0) in; per cell the packed upper triangle of the
@@ -969,6 +980,10 @@ __device__ __forceinline__ uint32_t sel4u(uint32_t v0, uint32_t v1, uint32_t v2,
 //             (partial Cholesky of [lc f_T; f_T^T 0] over the cbs cell pivots); the packed Schur complement and the
 //             condensed right-hand side are the only output -- or, given the face unknowns, the recovered cell unknowns.
 enum { MODE_LC = 0, MODE_SPLIT = 1, MODE_COND = 2 };
+// hho_pre.hpp: the head of one cell in the registers of the calling lane, its record to `out` (pairs 16 doubles apart)
+template <class C>
+__device__ __forceinline__ void cell_pre_record(const QuadTables *__restrict__ tab, const double *__restrict__ points,
+                                                const uint32_t *__restrict__ ptids, size_t cell, double *out);
 template <class C, int MODE>
 __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hho_local_ops_kernel(LocalOpsArgs a)
 {
@@ -1201,6 +1216,19 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
     // consecutive cells, so that the 8 cells of a record tile, and the lines of lc they share, meet in one L2.
     const size_t lblock = (PA_XCD_MAP && gridDim.x % 8 == 0) ? (size_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (size_t)blockIdx.x;
     const size_t stride = (size_t)gridDim.x * C::CPW;
+    // Cfg::SELF_PRE: the wavefront's own ring of 64 records; pass `it` of the block reads the slots (it mod SELF_IT) CPW + g
+    constexpr bool SELF = C::SELF_PRE;
+    constexpr int SELF_IT = C::SELF_IT;
+    double *ring = SELF ? a.pre_ring + (size_t)blockIdx.x * (size_t)(64 * PRE::NPRE) : nullptr;
+    auto rec_issue_slot = [&](int ib) {
+        const uint32_t s = (uint32_t)(ib * C::CPW + g);
+        const double *pc = ring + (s >> 3) * (uint32_t)(PRE::NP2 * 16) + (s & 7u) * 2u;
+#pragma unroll
+        for (int t = 0; t < C::PLC; ++t) {
+            const int e2 = l0 + t * G;
+            rec[t] = *reinterpret_cast<const double2 *>(pc + 16 * (e2 < PRE::NP2 ? e2 : 0));
+        }
+    };
     auto rec_issue = [&](size_t b) {
         // records lie in tiles of 8 cells, [tile][pair][cell % 8] (hho_pre.hpp): the pairs of one record are 128 bytes apart
         // (b is a multiple of the CPW cells of a wavefront, CPW divides 8: the wavefront's cells share a tile, whose address is
@@ -1232,15 +1260,34 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             for (int e = l; e < C::LGR * LD; e += G) S[C::oLG + e] = 0.0;
             wave_sync();
         }
-        rec_issue(lblock * C::CPW);
-        rec_deposit();
-        wave_sync();
+        if (!SELF) {
+            rec_issue(lblock * C::CPW);
+            rec_deposit();
+            wave_sync();
+        }
     }
 
 #ifdef PA_STAGE_CLOCK
     long long tk_sum[PA_NSTAGE] = {0}, tk_last = clock64();
 #endif
-    for (size_t base = lblock * C::CPW; base < a.n; base += stride) {
+    int it = 0;
+    for (size_t base = lblock * C::CPW; base < a.n; base += stride, ++it) {
+        const int ib = SELF ? it % SELF_IT : 0;
+        if (SELF && ib == 0) {
+            // the heads of the next 64 cells of this wavefront, one per lane: lane j's cell is the one group j % CPW of pass
+            // it + j / CPW will work on.  Every record of the previous batch has been consumed (the last one was deposited in
+            // region P a pass ago), so the ring is free.  Own stores, then own loads: s_waitcnt vmcnt(0) orders them (the vector
+            // L1 is write-through and the lines belong to this compute unit alone).
+            PA_MARK("SELFPRE");
+            const size_t idx = base + (size_t)(lane / C::CPW) * stride + (size_t)(lane % C::CPW);
+            if (idx < a.n)
+                cell_pre_record<C>(tab, a.points, a.ptids, a.first + idx,
+                                   ring + ((uint32_t)lane >> 3) * (uint32_t)(PRE::NP2 * 16) + ((uint32_t)lane & 7u) * 2u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            rec_issue_slot(0);
+            rec_deposit();
+            wave_sync();
+        }
         // Re-derive the lane index opaquely per cell: otherwise LICM hoists the index computations
         // of every stage out of the cell loop and the kernel spills.
         int l = l0;
@@ -1277,7 +1324,8 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         int bad_pre = 0;
         if (C::USE_PRE) {
             // the per-cell head comes from the pre-pass; its record is in region P already (prefetched)
-            rec_issue(base + stride);
+            if (!SELF) rec_issue(base + stride);
+            else if (ib + 1 < SELF_IT) rec_issue_slot(ib + 1);
             const double2 bb = lds_pair(S + C::oSU + 4), ib = lds_pair(S + C::oSU + 6);
             barx = bb.x; bary = bb.y; ih = ib.x; bad_pre = (int)ib.y;
         } else {
@@ -1898,7 +1946,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 t11s[gi] = su * su;
             }
         }
-        if (C::USE_PRE && (!COND || C::COND_OWN_P)) rec_deposit();
+        if (C::USE_PRE && (!COND || C::COND_OWN_P) && (!SELF || ib + 1 < SELF_IT)) rec_deposit();
         // condensed mode: the cell's right-hand side (lanes < CBS) and, for the recovery, its face unknowns (lanes < NF),
         // one value per lane, in flight during the product
         double fT_l = 0.0, uF_l = 0.0;
@@ -2269,7 +2317,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                     if (valid && a.uT != nullptr && l < CBS) a.uT[rel(CBS) + l] = t;
                 }
                 wave_sync();      // every read of the image is done
-                if (C::USE_PRE && !C::COND_OWN_P) { rec_deposit(); wave_sync(); }      // the next cell's record, into its place in region P
+                if (C::USE_PRE && !C::COND_OWN_P && (!SELF || ib + 1 < SELF_IT)) { rec_deposit(); wave_sync(); }      // the next cell's record, into its place in region P
             } else if (DIRECT) {
                 wave_sync();      // the next cell's tables overwrite Z
             } else if (EARLY_OUT) {

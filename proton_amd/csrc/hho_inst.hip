@@ -27,7 +27,7 @@
      "hho_local_ops<cd=" PA_STR(PA_CD) ",fd=" PA_STR(PA_FD) ",quad=" PA_STR(PA_QUAD) ",stab=" #STAB ",G=" #G ">",                \
      pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::WAVES,                                                \
      pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::USE_PRE ? &pa::launch_pre<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>> : nullptr, \
-     pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::Pre::NPRE, COND}
+     pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::Pre::NPRE, pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::SELF_PRE ? 1 : 0, COND}
 #define PA_ENTRIES_G(G) PA_ENTRY(0, G, PA_COND_NONE), PA_ENTRY(1, G, PA_COND_OF(1, G)), PA_ENTRY(2, G, PA_COND_OF(2, G))
 
 static const pa::KernelEntry k_entries[] = {

@@ -19,6 +19,7 @@ struct KernelEntry {
     int waves_per_simd;        // the occupancy the instance is tuned for (Cfg::WAVES): the grid does not exceed it
     pre_launcher launch_pre;   // the one-thread-per-cell pre-pass the kernel consumes (nullptr: all-in-one kernel)
     int pre_doubles;           // doubles per cell of its record (Cfg::Pre::NPRE)
+    int self_pre;              // Cfg::SELF_PRE: the cooperative kernel forms the records itself, into one ring of 64 per block (no pre-pass launch)
     // condensed mode (static condensation fused behind the product; nullptr without a stabilization: A_TT singular)
     local_ops_launcher launch_cond;
     const void *func_cond;

@@ -29,15 +29,18 @@ struct PreArgs {
     double *pre;
 };
 
+// The head of ONE cell, all of it in the registers of the calling lane; `out` = where pair 0 of the cell's record goes, the
+// other 16-byte pairs follow at a stride of 16 doubles (the tiles of 8 records described below).  Called by the pre-pass
+// kernel (one thread per cell of a piece) and, in the instances built with PA_SELF_PRE, by the cooperative kernel itself: there a
+// wavefront stops every 64 / CPW passes and forms the heads of the 64 cells it will visit next, one per lane, into a ring of 64
+// records of its own (hho_device.hpp).
 template <class C>
-__global__ __launch_bounds__(64, PA_PRE_WAVES) void hho_cell_pre_kernel(PreArgs a)
+__device__ __forceinline__ void cell_pre_record(const QuadTables *__restrict__ tab, const double *__restrict__ points,
+                                                const uint32_t *__restrict__ ptids, size_t cell, double *out)
 {
     constexpr int RD = C::RD, NR = C::NR, NPW = C::NPW, NMOM = C::NMOM;
     typedef typename C::Pre PL;
-    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= a.n) return;
-    const size_t cell = a.first + i;
-    const QuadTables *__restrict__ tab = a.tab;
+    struct { const double *points; const uint32_t *ptids; } a = {points, ptids};
 
     // ---- geometry (the same expressions as S0 of the cooperative kernel)
     const uint4 idv = *reinterpret_cast<const uint4 *>(a.ptids + 4 * cell);
@@ -77,7 +80,6 @@ __global__ __launch_bounds__(64, PA_PRE_WAVES) void hho_cell_pre_kernel(PreArgs 
     // tile write one full 128-byte line per store instruction (one record per lane, 496-byte stride, made every
     // 16-byte piece its own request at the L2: 0.23 ms of the k = 2 pre-pass was that); the consumer reads a record
     // as pairs 128 bytes apart, one cell ahead of its use.
-    double *out = a.pre + (((i >> 3) * (size_t)PL::NP2) * 8 + (i & 7)) * 2;
     auto put = [&](int e, double2 v) { *reinterpret_cast<double2 *>(out + (e / 2) * 16) = v; };
     {
         double su[4];
@@ -257,6 +259,15 @@ __global__ __launch_bounds__(64, PA_PRE_WAVES) void hho_cell_pre_kernel(PreArgs 
         for (int e = 0; e + 1 < NT; e += 2) put(PL::oMR + e, double2{tail[e], tail[e + 1]});
     }
     put(PL::oSCAL + 16, double2{(double)flags, (double)badm});
+}
+
+template <class C>
+__global__ __launch_bounds__(64, PA_PRE_WAVES) void hho_cell_pre_kernel(PreArgs a)
+{
+    typedef typename C::Pre PL;
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n) return;
+    cell_pre_record<C>(a.tab, a.points, a.ptids, a.first + i, a.pre + (((i >> 3) * (size_t)PL::NP2) * 8 + (i & 7)) * 2);
 }
 
 }  // namespace pa

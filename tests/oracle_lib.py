@@ -193,6 +193,18 @@ def lib():
     L.cut_interface_cell_offset.restype = C.c_size_t
     L.cut_interface_cell_offset.argtypes = [C.c_void_p, Degrees, C.c_size_t, i64p, C.c_int]
     L.cut_make_rhs.argtypes = [C.c_void_p, lsp, C.c_size_t, C.c_int, C.c_int, SCALAR_FN, SCALAR_FN, C.c_void_p, dp]
+    # ---- cut_truth.c (binary128 evaluation of the cut operators)
+    L.cut_truth_laplacian.argtypes = [C.c_void_p, lsp, C.c_size_t, Degrees, C.c_int, dp, dp]
+    L.cut_truth_stabilization.argtypes = [C.c_void_p, C.c_size_t, Degrees, C.c_int, dp]
+    L.cut_truth_rhs.argtypes = [C.c_void_p, lsp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+    L.cut_truth_laplacian_interface.argtypes = [C.c_void_p, lsp, C.c_size_t, Degrees, C.POINTER(CutParams), dp, dp]
+    L.cut_truth_rhs_side.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, dp]
+    L.cut_truth_last_interface_cond.restype = C.c_double
+    L.cut_truth_last_interface_cond.argtypes = []
+    L.cut_truth_round_inputs.restype = None
+    L.cut_truth_round_inputs.argtypes = [C.c_int]
+    L.cut_truth_laplacian_cond.restype = C.c_double
+    L.cut_truth_laplacian_cond.argtypes = [C.c_void_p, lsp, C.c_size_t, Degrees, C.c_int]
     _LIB = L
     return L
 
@@ -523,6 +535,43 @@ class CutMesh:
         st = self.L.cut_make_rhs(self.h, C.byref(self.ls), c, degree, where, self.L.hho_builtin_fn(f_id),
                                  self.L.hho_builtin_fn(bcs_id), None, _dp(out))
         return st, out
+
+    # ---- the same operators in binary128 from the same double quadrature lists (oracle/cut_truth.c): what sliver cells
+    # are judged against.  Same return shapes as laplacian / cut_stabilization / rhs / laplacian_interface / rhs_side.
+    def truth_laplacian(self, c, di, where=CUT_NEG):
+        ms, rbs = di.msize, di.rbs
+        oper = np.zeros((ms, rbs))
+        data = np.zeros((ms, ms))
+        st = self.L.cut_truth_laplacian(self.h, C.byref(self.ls), c, di, where, _dp(oper), _dp(data))
+        return st, oper.T.copy(), data.T.copy()
+
+    def truth_stabilization(self, c, di, where=CUT_NEG):
+        ms = di.msize
+        stab = np.zeros((ms, ms))
+        st = self.L.cut_truth_stabilization(self.h, c, di, where, _dp(stab))
+        return st, stab.T.copy()
+
+    def truth_rhs(self, c, degree, where=CUT_NEG, f_id=1, bcs_id=2):
+        out = np.zeros((degree + 2) * (degree + 1) // 2)
+        st = self.L.cut_truth_rhs(self.h, C.byref(self.ls), c, degree, where, f_id, bcs_id, _dp(out))
+        return st, out
+
+    def truth_laplacian_interface(self, c, di, kappa_1=1.0, kappa_2=1.0, eta=5.0):
+        ms2, rb2 = 2 * di.msize, 2 * di.rbs
+        oper = np.zeros((ms2, rb2))
+        data = np.zeros((ms2, ms2))
+        prm = CutParams(kappa_1, kappa_2, eta)
+        st = self.L.cut_truth_laplacian_interface(self.h, C.byref(self.ls), c, di, C.byref(prm), _dp(oper), _dp(data))
+        self.last_interface_cond = float(self.L.cut_truth_last_interface_cond())
+        return st, oper.T.copy(), data.T.copy()
+
+    def truth_rhs_side(self, c, degree, where, f_id=1):
+        out = np.zeros((degree + 2) * (degree + 1) // 2)
+        st = self.L.cut_truth_rhs_side(self.h, c, degree, where, f_id, _dp(out))
+        return st, out
+
+    def truth_cond(self, c, di, where=CUT_NEG):
+        return float(self.L.cut_truth_laplacian_cond(self.h, C.byref(self.ls), c, di, where))
 
     def agglo_set(self):
         a = np.zeros(self.nc, dtype=np.int8)

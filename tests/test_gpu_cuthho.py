@@ -21,6 +21,57 @@ def nerr(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
+def judge_cut_cells(ref, oracle, di, cells, got_lc, got_oper=None, got_data=None, label=""):
+    """Every cut cell against the binary128 evaluation of the reference's formulas from the same double quadrature lists
+    (oracle/cut_truth.c, pinned by the 50-digit fixtures of tests/golden/cut_ops.npz), next to the double-precision oracle
+    (the reference's operation order) judged the same way.  The Nitsche-penalised rbs x rbs system of a sliver is badly
+    conditioned (1-norm condition numbers to 1.9e9 on the 512 x 512 mesh): merely ROUNDING gr_lhs / gr_rhs to double and
+    solving exactly costs up to 1e-11 in `data` there (tests/test_oracle_cut_truth.py), so no double evaluation -- Eigen's,
+    the oracle's, the kernel's -- is within 1e-12 of another on those cells.  Asserted:
+      * 1e-12 on every cell whose condition number allows it (cond < 1e5), for lc, data and oper alike;
+      * on every cell the envelope the reference's own operation order stays inside, 1e-12 + 1e-15 cond (lc, data);
+      * the kernel is not the worse side: over the cells where either error exceeds 1e-13 the geometric mean of
+        err_gpu / err_oracle is <= 2 (two independent roundings of cond * eps differ cell by cell, in either direction);
+      * and it loses no more cells beyond 1e-12 than the oracle does (+ 2 %).
+    -> dict of the per-cell arrays (printed by the caller)."""
+    rows = []
+    for i, c in enumerate(cells):
+        c = int(c)
+        st, t_oper, t_data = ref.truth_laplacian(c, di)
+        assert st == 0
+        st, t_stab = ref.truth_stabilization(c, di)
+        assert st == 0
+        st, o_oper, o_data = ref.laplacian(c, di)
+        st, o_stab = ref.cut_stabilization(c, di)
+        t_lc = t_data + t_stab
+        e_gpu = nerr(got_lc[i], t_lc)
+        e_orc = nerr(o_data + o_stab, t_lc)
+        e_gd = nerr(got_data[i], t_data) if got_data is not None else 0.0
+        e_go = nerr(got_oper[i], t_oper) if got_oper is not None else 0.0
+        e_oo = nerr(o_oper, t_oper)
+        rows.append((ref.truth_cond(c, di), e_gpu, e_orc, e_gd, e_go, e_oo))
+    r = np.array(rows)
+    cond, e_gpu, e_orc, e_gd, e_go, e_oo = r.T
+    n_g, n_o = int((e_gpu > TOL).sum()), int((e_orc > TOL).sum())
+    worse = int((e_gpu > np.maximum(TOL, 2 * e_orc)).sum())
+    print("%s cut cells %d | cond median %.1e max %.1e | lc vs binary128: GPU median %.1e max %.1e, oracle median %.1e max %.1e | "
+          "beyond 1e-12: GPU %d, oracle %d | GPU worse than 2x oracle (and > 1e-12): %d | oper: GPU max %.1e, oracle max %.1e"
+          % (label, len(cells), np.median(cond), cond.max(), np.median(e_gpu), e_gpu.max(), np.median(e_orc), e_orc.max(),
+             n_g, n_o, worse, e_go.max(), e_oo.max()))
+    ok = cond < 1e5
+    assert np.all(e_gpu[ok] < TOL) and np.all(e_gd[ok] < TOL), (e_gpu[ok].max(), e_gd[ok].max())
+    assert np.all(e_go[cond < 1e3] < TOL)                      # oper itself carries the full cond * eps
+    env = TOL + 1e-15 * cond
+    assert np.all(e_gpu < env) and np.all(e_gd < env), (np.max(e_gpu / env), np.max(e_gd / env))
+    assert np.all(e_go < TOL + 1e-14 * cond), np.max(e_go / (TOL + 1e-14 * cond))
+    big = np.maximum(e_gpu, e_orc) > 1e-13
+    gm = float(np.exp(np.mean(np.log(e_gpu[big] / e_orc[big])))) if big.any() else 1.0
+    print("   geometric mean of err_gpu / err_oracle over the %d cells beyond 1e-13: %.2f" % (int(big.sum()), gm))
+    assert gm <= 2.0, gm
+    assert n_g <= n_o + max(1, len(cells) // 50), (n_g, n_o)
+    return dict(cond=cond, e_gpu=e_gpu, e_orc=e_orc)
+
+
 @pytest.mark.parametrize("N,k,r", [(10, 0, 4), (10, 1, 4), (20, 2, 4), (16, 1, 2), (12, 2, 5)])
 def test_cut_operators_match_oracle(asm, oracle, N, k, r):
     from proton_amd.batch import to_rowcol
@@ -37,20 +88,38 @@ def test_cut_operators_match_oracle(asm, oracle, N, k, r):
     di = oracle.degrees(k + 1, k)
     oper, data, stab, lc, rhs = (to_rowcol(out["oper"]), to_rowcol(out["data"]), to_rowcol(out["stab"]),
                                  to_rowcol(out["lc"]), out["rhs"].cpu().numpy())
-    errs = []
     for i, c in enumerate(cut_cells):
         st, o_oper, o_data = ref.laplacian(int(c), di)
         assert st == 0 and o_oper.shape == oper[i].shape
+        # stabilization and right-hand side involve no badly conditioned solve: rounding level against the oracle AND
+        # against the binary128 evaluation on every cell
         st, o_stab = ref.cut_stabilization(int(c), di)
         st, o_rhs = ref.rhs(int(c), di.cell_deg)
-        # The Nitsche-penalised rbs x rbs system of a sliver cut is badly conditioned (the cut part of
-        # the cell can be a tiny fraction of it): both sides carry cond * eps, so the bound is looser
-        # than for regular cells; the median over the cut cells must still be at rounding level.
-        errs.append(max(nerr(oper[i], o_oper), nerr(data[i], o_data), nerr(lc[i], o_data + o_stab)))
-        assert errs[-1] < 5e-9, (int(c), errs[-1])
-        assert nerr(stab[i], o_stab) < TOL
+        st, t_stab = ref.truth_stabilization(int(c), di)
+        st, t_rhs = ref.truth_rhs(int(c), di.cell_deg)
+        assert nerr(stab[i], o_stab) < TOL and nerr(stab[i], t_stab) < TOL
         assert np.abs(rhs[i] - o_rhs).max() < 1e-12 * max(1.0, np.abs(o_rhs).max())
-    assert np.median(errs) < 1e-11, np.median(errs)
+        assert np.abs(rhs[i] - t_rhs).max() < 1e-12 * max(1.0, np.abs(t_rhs).max())
+    res = judge_cut_cells(ref, oracle, di, cut_cells, lc, oper, data, label="N=%d k=%d r=%d:" % (N, k, r))
+    assert np.median(res["e_gpu"]) < 1e-13
+
+
+@pytest.mark.parametrize("N,k,r", [(20, 2, 4), (12, 1, 3)])
+def test_cut_quadrature_lists_are_the_oracles_bit_for_bit(asm, oracle, N, k, r):
+    """pa_cut_quadrature_points (the lists the cut kernel integrates with) == the oracle's restatement of
+    cuthho_geom.hpp:798-815, 851-895 bit for bit -- the binary128 side and the 50-digit fixtures take the oracle's lists as
+    their inputs, so this is what makes them the judge of the KERNEL's cells too."""
+    asm.cut_preprocess(N, refsteps=r)
+    ref = oracle.CutMesh(N, refsteps=r)
+    cut_cells = np.nonzero(ref.cell_loc == oracle.CUT_ON_INTERFACE)[0]
+    for where in (oracle.CUT_NEG, oracle.CUT_POS):
+        for which, fn, deg in ((0, ref.cell_quadrature, 2 * (k + 1)), (1, ref.interface_quadrature, 2 * (k + 1)),
+                               (2, ref.interface_quadrature, k + 1)):
+            off, xyw = asm.ctx.cut_quadrature_points(k, where, which)
+            assert len(off) == len(cut_cells) + 1
+            for i, c in enumerate(cut_cells):
+                want = np.array(fn(int(c), deg, where)).T.reshape(-1, 3)
+                assert np.array_equal(xyw[off[i]:off[i + 1]], want), (where, which, int(c))
 
 
 @pytest.mark.parametrize("N,k", [(10, 0), (20, 1), (20, 2)])
@@ -131,8 +200,12 @@ def test_cut_error_codes(asm):
                                          (12, 1, 3, (1.0, 7.5)), (10, 2, 5, (2.0, 0.5))])
 def test_interface_operators_match_oracle(asm, oracle, N, k, r, kappa):
     """make_hho_laplacian_interface + the stabilization blocks + both right-hand sides of every cut
-    cell, and the kappa-weighted uncut cells, against the oracle.  `oper` is compared modulo the
-    kernel vector of gr_lhs (the reference's LDLT leaves that component to rounding)."""
+    cell, and the kappa-weighted uncut cells.  Uncut cells: 1e-12 against the oracle.  Cut cells: `data` against the
+    binary128 evaluation (oracle/cut_truth.c), next to the oracle's pivoted LDL^T judged the same way -- the two-sided
+    system holds both parts of the cell, so one of them is a sliver wherever the other is regular, and no two double
+    evaluations agree to 1e-12 there (see judge_cut_cells).  `oper`: the product returns the solution with the constant of
+    the negative side pinned to zero, the representative the binary128 side returns too -- compared
+    directly; against the oracle (whose LDL^T leaves the kernel component e_0 + e_rbs to rounding) modulo that vector."""
     import cuthho_driver as cd
     from proton_amd.batch import to_rowcol
     ncut = asm.cut_preprocess(N, refsteps=r)
@@ -148,7 +221,7 @@ def test_interface_operators_match_oracle(asm, oracle, N, k, r, kappa):
     cut_cells = np.nonzero(ref.cell_loc == oracle.CUT_ON_INTERFACE)[0]
     assert ncut == len(cut_cells)
     rbs = di.rbs
-    errs = []
+    rows = []
     for c in range(ref.nc):
         w_lc, w_rhs = want[c]
         if ref.cell_loc[c] != oracle.CUT_ON_INTERFACE:
@@ -157,19 +230,35 @@ def test_interface_operators_match_oracle(asm, oracle, N, k, r, kappa):
         i = int(asm.cut_index[c])
         st, o_oper, o_data = ref.laplacian_interface(int(c), di, kappa[0], kappa[1])
         assert st == 0 and o_oper.shape == operc[i].shape
+        st, t_oper, t_data = ref.truth_laplacian_interface(int(c), di, kappa[0], kappa[1])
+        assert st == 0
         d = operc[i] - o_oper                          # must be (row 0 + row rbs) * const per column
         shift = d[0].copy()
         d[0] -= shift; d[rbs] -= shift
         assert np.abs(operc[i][0]).max() == 0.0        # the pinned unknown
-        errs.append((nerr(datac[i], o_data), nerr(lcc[i], w_lc), np.abs(d).max() / np.abs(o_oper).max()))
-        assert max(errs[-1]) < 5e-9, (int(c), errs[-1])
+        # lc = data + the two stabilizations scattered (:1694-1705): the stabilizations are at rounding level, so the
+        # error of lc against the oracle's lc is the error of data
+        rows.append((nerr(datac[i], t_data), nerr(o_data, t_data), nerr(operc[i], t_oper), np.abs(d).max() / np.abs(o_oper).max(),
+                     nerr(lcc[i] - datac[i], w_lc - o_data), ref.last_interface_cond))
+        for side, where in enumerate((oracle.CUT_NEG, oracle.CUT_POS)):
+            st, t_rhs = ref.truth_rhs_side(int(c), di.cell_deg, where)
+            assert np.abs(rhsc[i][side * di.cbs:(side + 1) * di.cbs] - t_rhs).max() < 1e-12 * max(1.0, np.abs(t_rhs).max())
         assert np.abs(rhsc[i] - w_rhs).max() < 1e-12 * max(1.0, np.abs(w_rhs).max())
-    # As for the one-sided cut operators, slivers make the (2 rbs - 1) system badly conditioned and both
-    # sides carry cond * eps (the oracle through a pivoted LDL^T, the GPU through Cholesky of the
-    # pinned system): rounding level is asserted on the median over the cut cells.
-    med = np.median(np.array(errs), axis=0)
-    print("median errors (data, lc, oper mod kernel):", med)
-    assert med[0] < 5e-12 and med[1] < 5e-12 and med[2] < 1e-10, med
+    e_gpu, e_orc, e_oper, e_oper_mod, e_stab, cond = np.array(rows).T
+    print("interface N=%d k=%d: cut cells %d | cond (pinned two-sided system) median %.1e max %.1e | data vs binary128: GPU median %.1e max %.1e, "
+          "oracle median %.1e max %.1e | beyond 1e-12: GPU %d, oracle %d | oper vs binary128 max %.1e"
+          % (N, k, len(rows), np.median(cond), cond.max(), np.median(e_gpu), e_gpu.max(), np.median(e_orc), e_orc.max(),
+             (e_gpu > TOL).sum(), (e_orc > TOL).sum(), e_oper.max()))
+    assert np.all(e_stab < TOL)
+    assert np.all(e_gpu[cond < 1e5] < TOL)
+    assert np.all(e_gpu < TOL + 1e-15 * cond), np.max(e_gpu / (TOL + 1e-15 * cond))
+    big = np.maximum(e_gpu, e_orc) > 1e-13
+    gm = float(np.exp(np.mean(np.log(e_gpu[big] / e_orc[big])))) if big.any() else 1.0
+    print("   geometric mean of err_gpu / err_oracle over the %d cells beyond 1e-13: %.2f" % (int(big.sum()), gm))
+    assert gm <= 2.0, gm
+    assert np.all(e_oper < TOL + 1e-14 * cond) and np.all(e_oper_mod < TOL + 1e-13 * cond)
+    # (the pinned two-sided system is badly conditioned on EVERY cut cell -- median 1e7 at k = 2 --: the median error follows)
+    assert np.median(e_gpu) <= 2 * np.median(e_orc) + 1e-14 and np.median(e_gpu) < 1e-12
 
 
 @pytest.mark.parametrize("N,k", [(10, 1), (20, 2)])
@@ -255,13 +344,10 @@ def test_agglomeration_branch_matches_oracle(asm, oracle, N):
     out = asm.cut_local_ops(1)
     asm.synchronize()
     lc = to_rowcol(out["lc"])
-    errs = []
-    for i, c in enumerate(np.nonzero(ref.cell_loc == oracle.CUT_ON_INTERFACE)[0]):
-        st, o_oper, o_data = ref.laplacian(int(c), di)
-        st, o_stab = ref.cut_stabilization(int(c), di)
-        errs.append(nerr(lc[i], o_data + o_stab))
-    # without node displacement the cuts can be arbitrarily bad (that is what the classes flag): cond * eps on both sides
-    assert np.median(errs) < 1e-11 and max(errs) < 1e-6, (np.median(errs), max(errs))
+    # without node displacement the cuts can be arbitrarily bad (that is what the classes flag): judged against binary128 with the
+    # same condition-number envelope as the displaced meshes
+    res = judge_cut_cells(ref, oracle, di, np.nonzero(ref.cell_loc == oracle.CUT_ON_INTERFACE)[0], lc, label="agglomeration branch N=%d k=1:" % N)
+    assert np.median(res["e_gpu"]) < 1e-12
 
 
 def test_interface_assembler_without_cut_cells_is_the_plain_assembler(asm):
@@ -312,30 +398,30 @@ def test_config3_at_full_size_cut_cells_merged(asm, oracle):
     asym = (lc - lc.transpose(1, 2)).abs().amax(dim=(1, 2)) / scale
     is_cut = torch.from_numpy(ref.cell_loc == oracle.CUT_ON_INTERFACE).to(lc.device)
     assert float(asym[~is_cut].max()) < 1e-12
-    assert float(asym[is_cut].max()) < 1e-9          # slivers: cond * eps of the Nitsche-penalised system (see the test above)
+    assert float(asym[is_cut].max()) < 1e-9          # slivers: cond * eps of the Nitsche-penalised system (judge_cut_cells)
     outside = torch.from_numpy(ref.cell_loc == oracle.CUT_POS).to(lc.device)
     assert int(outside.sum()) > 0 and float(rhs[outside].abs().max()) == 0.0
     assert float(rhs[~outside].abs().amax(dim=1).min()) > 0.0
     di = oracle.degrees(k + 1, k)
     rng = np.random.default_rng(512)
-    sample_cut = np.sort(rng.choice(cut_cells, size=96, replace=False))
     uncut = np.nonzero(ref.cell_loc != oracle.CUT_ON_INTERFACE)[0]
     sample_uncut = np.sort(rng.choice(uncut, size=256, replace=False))
-    lch, rhsh = to_rowcol(lc[torch.from_numpy(np.r_[sample_cut, sample_uncut]).to(lc.device)]), rhs.cpu().numpy()
-    errs = []
-    for i, c in enumerate(np.r_[sample_cut, sample_uncut]):
+    rhsh = rhs.cpu().numpy()
+    lcu = to_rowcol(lc[torch.from_numpy(sample_uncut).to(lc.device)])
+    for i, c in enumerate(sample_uncut):
         st, o_oper, o_data = ref.laplacian(int(c), di)
         assert st == 0
         st, o_stab = ref.cut_stabilization(int(c), di)
         st, o_rhs = ref.rhs(int(c), di.cell_deg)
-        e = nerr(lch[i], o_data + o_stab)
-        if i < len(sample_cut):
-            errs.append(e)
-            assert e < 5e-9, (int(c), e)
-        else:
-            assert e < TOL, (int(c), e)
+        assert nerr(lcu[i], o_data + o_stab) < TOL, int(c)
         assert np.abs(rhsh[c] - o_rhs).max() < 1e-12 * max(1.0, np.abs(o_rhs).max())
-    assert np.median(errs) < 1e-11, np.median(errs)
+    # EVERY one of the cut cells against the binary128 evaluation (and the oracle judged the same way, cell for cell)
+    lcc = to_rowcol(lc[torch.from_numpy(cut_cells).to(lc.device)])
+    for i, c in enumerate(cut_cells):
+        st, t_rhs = ref.truth_rhs(int(c), di.cell_deg)
+        assert np.abs(rhsh[c] - t_rhs).max() < 1e-12 * max(1.0, np.abs(t_rhs).max())
+    res = judge_cut_cells(ref, oracle, di, cut_cells, lcc, label="config 3 (512 x 512, k = 2):")
+    assert np.median(res["e_gpu"]) < 1e-13
 
 
 @pytest.mark.parametrize("N,k", [(20, 1), (24, 2)])
