@@ -288,6 +288,22 @@ int pa_triplets_batch(pa_context *ctx, pa_degree_info di, size_t first, size_t n
                       int32_t *d_rows, int32_t *d_cols, double *d_vals,
                       int32_t *d_rhs_rows, double *d_rhs_vals);
 
+/* The same system -- assembler<Mesh>'s own numbering, cell AND face unknowns (system_size = cbs * ncells + fbs *
+ * num_other_faces, hho.hpp:331), i.e. what assemble (hho.hpp:344-406) + finalize = setFromTriplets (hho.hpp:451-455)
+ * leave in `LHS` / `RHS` -- built DIRECTLY in CSR from the mesh's face adjacency: no triplets, no sort.  The span the
+ * reference's drivers print as "Matrix assembly" (apps/cuthho/cuthho_square.cpp:881-905,
+ * apps/convergence_test/convergence_test.cpp:201-217) is pa_local_ops_batch + pa_cell_rhs_batch + pa_assembler_csr_fill.
+ * Whole-mesh contexts only (a slab of a partitioned mesh assembles the face-only system: pa_condensed_*).
+ * Symbolic phase, once per mesh and degree: nrows = system_size, nnz; d_rowptr nrows + 1 (int64), d_colind nnz (int32,
+ * ascending within a row; may be NULL).  Numeric phase, once per assembly: d_values nnz, d_RHS nrows (may be NULL) from
+ * d_lc (ncells x msize^2), d_rhs (ncells x cbs or NULL), d_g (pa_dirichlet_data_batch or NULL).  Structure and values
+ * bit-identical to pa_csr_from_triplets of pa_triplets_batch, d_RHS to the scatter-add of its d_rhs_vals in cell order. */
+typedef struct { uint64_t nrows, nnz; } pa_assembler_csr_info;
+int pa_assembler_csr_query(pa_context *ctx, pa_degree_info di, pa_assembler_csr_info *out);
+int pa_assembler_csr_pattern(pa_context *ctx, pa_degree_info di, int64_t *d_rowptr, int32_t *d_colind);
+int pa_assembler_csr_fill(pa_context *ctx, pa_degree_info di, const double *d_lc, const double *d_rhs, const double *d_g,
+                          double *d_values, double *d_RHS);
+
 /* assembler::take_local_data (hho.hpp:408-449) for cells [first, first+n): d_out n x msize =
  * the cell's dofs of `d_solution` (system_size values), Dirichlet faces filled from d_g
  * (pa_dirichlet_data_batch; NULL = homogeneous). */
@@ -505,8 +521,11 @@ int pa_comm_neighbour_exchange_start(pa_comm *comm, const double *d_send_lo, siz
  *   neighbour_counts: at setup, tell the neighbours how many of their entries this rank reads (need_lo below, need_hi
  *                     above) and learn how many of this rank's first / last entries they read (give_lo, give_hi).
  * Callbacks return 0 on success.  d_b, d_x: the rank's own rows (row_end - row_begin doubles); x starts from zero.
- * *transport_status: 0 ok, 1 a callback failed, 2 the rows read beyond what the neighbours can give (or without a
- * transport beyond the own range). */
+ * *transport_status: 0 ok, 1 a callback failed on this rank, 2 this rank's rows read beyond what the neighbours can give (or,
+ * without a transport, beyond the own range), 3 ANOTHER rank failed, 4 a HIP error on this rank.  Every exit is collective: a
+ * rank's local failure rides as a flag on the next all-reduce (one extra addend: allreduce_sum is called with up to 3 values)
+ * and all ranks return from the same reduction -- PA_ERR_COMM (1, 3), PA_ERR_INVALID_ARG (2), PA_ERR_HIP (4) --, none is left
+ * inside a collective or a neighbour exchange. */
 typedef struct {
     void *user;
     int (*allreduce_sum)(void *user, double *vals, int n);

@@ -1,8 +1,8 @@
 """Build libproton_amd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
 One translation unit per (cell degree, face degree, quadrature kind) listed in
-csrc/pa_configs.def, compiled in parallel, plus csrc/capi.hip, csrc/csr.hip, csrc/solver.hip and
-csrc/condensed.hip; linked into
+csrc/pa_configs.def, compiled in parallel, plus csrc/capi.hip, csrc/csr.hip, csrc/solver.hip,
+csrc/condensed.hip, csrc/assembler_csr.hip and csrc/comm.hip; linked into
 proton_amd/lib/libproton_amd.so.  hipcc cross-compiles without a GPU.
 """
 import concurrent.futures
@@ -84,6 +84,21 @@ def _stamp(defs):
     return " ".join(FLAGS + defs)
 
 
+def build_stamp():
+    """sha256 (16 hex digits) of everything the shipped library is compiled from: every file of csrc/, the C ABI header, the
+    flags and the per-instance settings of this file.  bench.py prints it, counter files under profiles/ carry it, and a
+    counter entry is used only for the build it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in sorted(os.listdir(CSRC)):
+        with open(os.path.join(CSRC, n), "rb") as f:
+            h.update(n.encode()); h.update(f.read())
+    with open(os.path.join(HERE, "..", "include", "proton_amd.h"), "rb") as f:
+        h.update(f.read())
+    h.update(repr((FLAGS, sorted(PER_CONFIG_FLAGS.items()))).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale(obj, defs, newest):
     if not os.path.exists(obj) or os.path.getmtime(obj) < newest:
         return True
@@ -117,7 +132,7 @@ def build(force=False, verbose=False, jobs=None):
              else PER_CONFIG_FLAGS.get((cd, fd, q), []))
         if force or _stale(obj, defs, newest):
             todo.append((os.path.join(CSRC, "hho_inst.hip"), obj, defs))
-    for unit in ("capi", "csr", "solver", "condensed", "comm"):
+    for unit in ("capi", "csr", "solver", "condensed", "assembler_csr", "comm"):
         unit_obj = os.path.join(OBJ_DIR, unit + ".o")
         objs.append(unit_obj)
         if force or _stale(unit_obj, [], newest):

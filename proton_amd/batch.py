@@ -205,6 +205,26 @@ class BatchAssembler:
                           vals.data_ptr(), rhs_rows.data_ptr(), rhs_vals.data_ptr())
         return rows, cols, vals, rhs_rows, rhs_vals
 
+    def assembler_csr_pattern(self, cd, fd):
+        """assembler<Mesh>'s own system (cell + face unknowns) directly in CSR, symbolic phase -> (rowptr int64 [nrows+1], colind int32 [nnz])"""
+        di, _ = capi.degree_info(cd, fd)
+        info = self.ctx.assembler_csr_query(di)
+        rowptr = torch.empty(info.nrows + 1, dtype=torch.int64, device=self.device)
+        colind = torch.empty(max(info.nnz, 1), dtype=torch.int32, device=self.device)
+        self.ctx.assembler_csr_pattern(di, rowptr.data_ptr(), colind.data_ptr())
+        return rowptr, colind[:info.nnz]
+
+    def assembler_csr_fill(self, cd, fd, lc, rhs=None, g=None, values=None, RHS=None):
+        """numeric phase of the same -> (values [nnz], RHS [nrows])"""
+        di, _ = capi.degree_info(cd, fd)
+        info = self.ctx.assembler_csr_query(di)
+        if values is None:
+            values = torch.empty(max(info.nnz, 1), dtype=torch.float64, device=self.device)
+        if RHS is None:
+            RHS = torch.empty(max(info.nrows, 1), dtype=torch.float64, device=self.device)
+        self.ctx.assembler_csr_fill(di, lc.data_ptr(), _ptr(rhs), _ptr(g), values.data_ptr(), RHS.data_ptr())
+        return values[:info.nnz], RHS[:info.nrows]
+
     def csr_from_triplets(self, rows, cols, vals, nrows):
         """setFromTriplets on the device -> (rowptr int64 [nrows+1], colind int32 [nnz], values [nnz])."""
         rows, cols, vals = rows.reshape(-1), cols.reshape(-1), vals.reshape(-1)

@@ -34,6 +34,7 @@ EXPORTS = [
     "pa_cut_interface_ops_batch", "pa_cut_interface_uncut_batch", "pa_interface_assembler_query",
     "pa_interface_triplets_batch", "pa_interface_cell_offsets",
     "pa_condensed_ops_batch", "pa_condensed_recover_batch", "pa_condensed_query", "pa_condensed_triplets_batch",
+    "pa_assembler_csr_query", "pa_assembler_csr_pattern", "pa_assembler_csr_fill",
     "pa_condensed_csr_pattern", "pa_condensed_csr_fill", "pa_condensed_halo_pack", "pa_condensed_take_faces",
     "pa_condensed_expand_solution", "pa_condensed_launch_info", "pa_condensed_partition_info",
     "pa_comm_unique_id", "pa_comm_create", "pa_comm_destroy", "pa_comm_info", "pa_comm_last_error",
@@ -78,6 +79,10 @@ class LaunchInfo(C.Structure):
 class AssemblerInfo(C.Structure):
     _fields_ = [("system_size", C.c_uint64), ("ncells_global", C.c_uint64), ("cell_base", C.c_uint64),
                 ("nfaces_local", C.c_uint64), ("face_base", C.c_uint64), ("num_other_faces", C.c_uint64)]
+
+
+class AssemblerCsrInfo(C.Structure):
+    _fields_ = [("nrows", C.c_uint64), ("nnz", C.c_uint64)]
 
 
 class CondensedInfo(C.Structure):
@@ -189,6 +194,9 @@ def lib():
     L.pa_condensed_recover_batch.argtypes = [vp, DegreeInfo, C.c_int, C.c_int, sz, sz, dp, dp, dp, dp]
     L.pa_condensed_query.argtypes = [vp, DegreeInfo, C.POINTER(CondensedInfo)]
     L.pa_condensed_triplets_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp, dp, dp, dp, dp, dp]
+    L.pa_assembler_csr_query.argtypes = [vp, DegreeInfo, C.POINTER(AssemblerCsrInfo)]
+    L.pa_assembler_csr_pattern.argtypes = [vp, DegreeInfo, dp, dp]
+    L.pa_assembler_csr_fill.argtypes = [vp, DegreeInfo, dp, dp, dp, dp, dp]
     L.pa_condensed_csr_pattern.argtypes = [vp, DegreeInfo, dp, dp]
     L.pa_condensed_csr_fill.argtypes = [vp, DegreeInfo, dp, dp, dp, dp, dp]
     L.pa_condensed_halo_pack.argtypes = [vp, DegreeInfo, dp, dp, dp]
@@ -537,6 +545,17 @@ class Context:
     def condensed_triplets(self, di, first, n, cond, g, rows, cols, vals, rhs_rows, rhs_vals):
         self._ck(self._L.pa_condensed_triplets_batch(self.h, di, first, n, cond, g, rows, cols, vals, rhs_rows, rhs_vals),
                  "pa_condensed_triplets_batch")
+
+    def assembler_csr_query(self, di):
+        out = AssemblerCsrInfo()
+        self._ck(self._L.pa_assembler_csr_query(self.h, di, C.byref(out)), "pa_assembler_csr_query")
+        return out
+
+    def assembler_csr_pattern(self, di, rowptr, colind):
+        self._ck(self._L.pa_assembler_csr_pattern(self.h, di, rowptr, colind), "pa_assembler_csr_pattern")
+
+    def assembler_csr_fill(self, di, lc, rhs, g, values, RHS):
+        self._ck(self._L.pa_assembler_csr_fill(self.h, di, lc, rhs, g, values, RHS), "pa_assembler_csr_fill")
 
     def condensed_csr_pattern(self, di, rowptr, colind):
         self._ck(self._L.pa_condensed_csr_pattern(self.h, di, rowptr, colind), "pa_condensed_csr_pattern")

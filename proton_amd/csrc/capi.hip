@@ -14,6 +14,7 @@
 #include "cut_device.hpp"
 #include "cut_interface_device.hpp"
 #include "condensed.hpp"
+#include "assembler_csr.hpp"
 #include "cut_host.hpp"
 #include "hho_assembly.hpp"
 #include "hho_aux.hpp"
@@ -112,6 +113,10 @@ struct pa_context {
     uint32_t cond_nown = 0, cond_owned_range = 0;
     int32_t cond_p0 = 0;
     uint64_t cond_total_cols = 0;             // sum of the column-face counts of the owned faces
+    // direct CSR of the assembler's own system (assembler_csr.hip): non-Dirichlet faces per cell / cells per face and their prefixes
+    uint32_t *d_asm_nfc = nullptr, *d_asm_cprefix = nullptr, *d_asm_nfcell = nullptr, *d_asm_fprefix = nullptr;
+    bool asm_ready = false;
+    uint64_t asm_cell_faces_total = 0, asm_face_cells_total = 0;
     // cutHHO state (host tags + device copies)
     pa::CutMeshHost *cut = nullptr;
     // device copies of the cut quadrature lists, built once per (face degree, side)
@@ -163,6 +168,11 @@ static void release_faces(pa_context *ctx)
     if (ctx->d_prefix) (void)hipFree(ctx->d_prefix);
     ctx->d_adj = nullptr; ctx->d_cfaces = nullptr; ctx->d_ncols = ctx->d_prefix = nullptr;
     ctx->cond_ready = false; ctx->cond_nown = ctx->cond_owned_range = 0; ctx->cond_p0 = 0; ctx->cond_total_cols = 0;
+    for (uint32_t **p : {&ctx->d_asm_nfc, &ctx->d_asm_cprefix, &ctx->d_asm_nfcell, &ctx->d_asm_fprefix}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    ctx->asm_ready = false; ctx->asm_cell_faces_total = ctx->asm_face_cells_total = 0;
     ctx->structured = false;
 }
 
@@ -721,12 +731,14 @@ int pa_conjugated_gradient_rows(pa_context *ctx, const pa_cg_transport *transpor
     pa::CgTransport tp{};
     if (transport) { tp.user = transport->user; tp.allreduce_sum = transport->allreduce_sum; tp.halo = transport->halo; tp.neighbour_counts = transport->neighbour_counts; }
     int reason = 0, tstat = 0;
-    PA_HIP(ctx, pa::conjugated_gradient_rows(ctx->stream, transport ? &tp : nullptr, row_begin, row_end, d_rowptr, d_colind, d_values, d_b, d_x,
-                                             convergence_threshold, divergence_threshold, max_iter, apply_preconditioner, &reason,
-                                             iterations, relative_residual, &tstat));
+    const hipError_t he = pa::conjugated_gradient_rows(ctx->stream, transport ? &tp : nullptr, row_begin, row_end, d_rowptr, d_colind, d_values,
+                                                       d_b, d_x, convergence_threshold, divergence_threshold, max_iter, apply_preconditioner,
+                                                       &reason, iterations, relative_residual, &tstat);
     if (exit_reason) *exit_reason = reason;
     if (transport_status) *transport_status = tstat;
-    return tstat == 1 ? PA_ERR_COMM : (tstat == 2 ? PA_ERR_INVALID_ARG : PA_OK);
+    if (he != hipSuccess) { ctx->last_error = std::string("pa_conjugated_gradient_rows: ") + hipGetErrorString(he); return PA_ERR_HIP; }
+    if (tstat == 3) ctx->last_error = "pa_conjugated_gradient_rows: another rank failed; every rank left the solve at the same reduction";
+    return (tstat == 1 || tstat == 3) ? PA_ERR_COMM : (tstat == 2 ? PA_ERR_INVALID_ARG : PA_OK);
 }
 
 int pa_copy_to_host(pa_context *ctx, void *host_dst, const void *d_src, size_t bytes)
@@ -835,6 +847,14 @@ static int run_local_ops(pa_context *ctx, pa_degree_info di, int quad_kind, int 
     if (const char *env = std::getenv("PA_ABLATE")) ablate = (uint32_t)std::strtoul(env, nullptr, 0);
 #endif
     const bool split = !o.cond && (d_data != nullptr || d_stab != nullptr);
+    // msize <= 9 and nothing but lc (and info) asked for: the thread-per-cell kernel of hho_small.hpp -- one launch, no record
+    if (e->launch_small && !o.cond && !split && d_oper == nullptr && d_lc != nullptr && ablate == 0) {
+        pa::SmallOpsArgs sa;
+        sa.tab = ctx->d_tab; sa.points = ctx->d_points; sa.ptids = ctx->d_ptids;
+        sa.first = first; sa.n = n; sa.lc = d_lc; sa.info = d_info;
+        PA_HIP(ctx, e->launch_small(sa, ctx->stream));
+        return PA_OK;
+    }
     // Kernels that take the per-cell head from the pre-pass run in pieces of at most `piece` cells: pre-pass of a
     // piece into the context's record buffer, then the cooperative kernel over the same cells (same stream).
     size_t piece = n;
@@ -1315,6 +1335,80 @@ int pa_condensed_csr_fill(pa_context *ctx, pa_degree_info di, const double *d_co
     PA_HIP(ctx, hipSetDevice(ctx->device));
     PA_HIP(ctx, pa::cond_fill(ctx->stream, cond_mesh(ctx), ctx->cond_nown, di.face_deg + 1, ctx->d_cfaces_lean, ctx->d_prefix, d_cond, d_g,
                               d_halo_below, d_values, d_rhs));
+    return PA_OK;
+}
+
+// ---- the assembler's own system (cell + face unknowns) directly in CSR: assembler_csr.hip ---------------------------
+static int asm_prepare(pa_context *ctx)
+{
+    const int st = cond_prepare(ctx);
+    if (st != PA_OK) return st;
+    if (ctx->structured && (ctx->sm.row0 != 0 || ctx->sm.row1 != ctx->sm.Ny)) {
+        ctx->last_error = "pa_assembler_csr_*: whole-mesh contexts only (a slab assembles the face-only system: pa_condensed_*)";
+        return PA_ERR_INVALID_ARG;
+    }
+    if (ctx->asm_ready) return PA_OK;
+    const uint32_t nc = (uint32_t)ctx->ncells, nown = ctx->cond_nown;
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_asm_nfc, ((size_t)nc + 1) * sizeof(uint32_t)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_asm_cprefix, ((size_t)nc + 1) * sizeof(uint32_t)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_asm_nfcell, ((size_t)nown + 1) * sizeof(uint32_t)));
+    PA_HIP(ctx, hipMalloc((void **)&ctx->d_asm_fprefix, ((size_t)nown + 1) * sizeof(uint32_t)));
+    PA_HIP(ctx, pa::asm_build_tables(ctx->stream, cond_mesh(ctx), nc, nown, ctx->d_cfaces_lean, ctx->d_asm_nfc, ctx->d_asm_cprefix,
+                                     ctx->d_asm_nfcell, ctx->d_asm_fprefix));
+    uint32_t a = 0, b = 0;
+    PA_HIP(ctx, hipMemcpy(&a, ctx->d_asm_cprefix + nc, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    PA_HIP(ctx, hipMemcpy(&b, ctx->d_asm_fprefix + nown, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    ctx->asm_cell_faces_total = a; ctx->asm_face_cells_total = b;
+    ctx->asm_ready = true;
+    return PA_OK;
+}
+
+static void asm_sizes(const pa_context *ctx, pa_degree_info di, uint64_t *cell_nnz, uint64_t *nnz, uint64_t *nrows)
+{
+    const uint64_t cbs = (uint64_t)(di.cell_deg + 2) * (di.cell_deg + 1) / 2, fbs = (uint64_t)di.face_deg + 1;
+    *cell_nnz = cbs * (ctx->ncells * cbs + ctx->asm_cell_faces_total * fbs);
+    *nnz = *cell_nnz + fbs * (ctx->asm_face_cells_total * cbs + ctx->cond_total_cols * fbs);
+    *nrows = cbs * ctx->ncells + fbs * ctx->num_other_faces;
+}
+
+int pa_assembler_csr_query(pa_context *ctx, pa_degree_info di, pa_assembler_csr_info *out)
+{
+    if (!ctx || !out || !cond_degree_ok(di)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    const int st = asm_prepare(ctx);
+    if (st != PA_OK) return st;
+    uint64_t cell_nnz;
+    asm_sizes(ctx, di, &cell_nnz, &out->nnz, &out->nrows);
+    return PA_OK;
+}
+
+int pa_assembler_csr_pattern(pa_context *ctx, pa_degree_info di, int64_t *d_rowptr, int32_t *d_colind)
+{
+    if (!ctx || !d_rowptr || !cond_degree_ok(di)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    const int st = asm_prepare(ctx);
+    if (st != PA_OK) return st;
+    uint64_t cell_nnz, nnz, nrows;
+    asm_sizes(ctx, di, &cell_nnz, &nnz, &nrows);
+    if (nrows >= ((uint64_t)1 << 31)) return PA_ERR_INVALID_ARG;                    // int32 column ids
+    PA_HIP(ctx, pa::asm_pattern(ctx->stream, cond_mesh(ctx), (di.cell_deg + 2) * (di.cell_deg + 1) / 2, di.face_deg + 1, (uint32_t)ctx->ncells,
+                                ctx->cond_nown, cell_nnz, ctx->d_cfaces, ctx->d_prefix, ctx->d_asm_cprefix, ctx->d_asm_fprefix, d_rowptr,
+                                d_colind));
+    return PA_OK;
+}
+
+int pa_assembler_csr_fill(pa_context *ctx, pa_degree_info di, const double *d_lc, const double *d_rhs, const double *d_g,
+                          double *d_values, double *d_RHS)
+{
+    if (!ctx || !d_lc || !d_values || !cond_degree_ok(di)) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    const int st = asm_prepare(ctx);
+    if (st != PA_OK) return st;
+    uint64_t cell_nnz, nnz, nrows;
+    asm_sizes(ctx, di, &cell_nnz, &nnz, &nrows);
+    PA_HIP(ctx, pa::asm_fill(ctx->stream, cond_mesh(ctx), (di.cell_deg + 2) * (di.cell_deg + 1) / 2, di.face_deg + 1, (uint32_t)ctx->ncells,
+                             ctx->cond_nown, cell_nnz, ctx->d_cfaces_lean, ctx->d_prefix, ctx->d_asm_cprefix, ctx->d_asm_fprefix, d_lc, d_rhs,
+                             d_g, d_values, d_RHS));
     return PA_OK;
 }
 

@@ -96,6 +96,13 @@ extern "C" __attribute__((visibility("hidden"))) int pa_context_device_(pa_conte
         if (r_ != 0) { (c)->last_error = std::string(#call) + ": " + rccl()->GetErrorString(r_); return PA_ERR_COMM; } \
     } while (0)
 
+static const ncclResult_t ncclSuccess = 0;
+static int comm_nccl_error(pa_comm *c, const char *what, ncclResult_t r)
+{
+    c->last_error = std::string(what ? what : "nccl") + ": " + rccl()->GetErrorString(r);
+    return PA_ERR_COMM;
+}
+
 extern "C" {
 
 int pa_comm_unique_id(void *id_out, size_t bytes)
@@ -188,9 +195,14 @@ int pa_comm_halo_exchange_start(pa_comm *c, const double *d_send_up, size_t send
     if (st != PA_OK) return st;
     Rccl *r = rccl();
     PA_CNCCL(c, r->GroupStart());
-    if (recv) PA_CNCCL(c, r->Recv(d_recv_below, recv_count, ncclFloat64, c->rank - 1, c->comm, c->side));
-    if (send) PA_CNCCL(c, r->Send(d_send_up, send_count, ncclFloat64, c->rank + 1, c->comm, c->side));
-    PA_CNCCL(c, r->GroupEnd());
+    // a failing Send / Recv must not leave the group open: remember the first error, close the group, then report it
+    ncclResult_t first = ncclSuccess;
+    const char *what = nullptr;
+    if (recv && first == ncclSuccess) { first = r->Recv(d_recv_below, recv_count, ncclFloat64, c->rank - 1, c->comm, c->side); what = "ncclRecv"; }
+    if (send && first == ncclSuccess) { first = r->Send(d_send_up, send_count, ncclFloat64, c->rank + 1, c->comm, c->side); what = "ncclSend"; }
+    const ncclResult_t ge = r->GroupEnd();
+    if (first != ncclSuccess) return comm_nccl_error(c, what, first);
+    if (ge != ncclSuccess) return comm_nccl_error(c, "ncclGroupEnd", ge);
     return comm_end(c);
 }
 
@@ -206,11 +218,15 @@ int pa_comm_neighbour_exchange_start(pa_comm *c, const double *d_send_lo, size_t
     if (st != PA_OK) return st;
     Rccl *r = rccl();
     PA_CNCCL(c, r->GroupStart());
-    if (r_lo) PA_CNCCL(c, r->Recv(d_recv_lo, n_recv_lo, ncclFloat64, c->rank - 1, c->comm, c->side));
-    if (r_hi) PA_CNCCL(c, r->Recv(d_recv_hi, n_recv_hi, ncclFloat64, c->rank + 1, c->comm, c->side));
-    if (s_lo) PA_CNCCL(c, r->Send(d_send_lo, n_send_lo, ncclFloat64, c->rank - 1, c->comm, c->side));
-    if (s_hi) PA_CNCCL(c, r->Send(d_send_hi, n_send_hi, ncclFloat64, c->rank + 1, c->comm, c->side));
-    PA_CNCCL(c, r->GroupEnd());
+    ncclResult_t first = ncclSuccess;              // (as above: the group is closed on every path)
+    const char *what = nullptr;
+    if (r_lo && first == ncclSuccess) { first = r->Recv(d_recv_lo, n_recv_lo, ncclFloat64, c->rank - 1, c->comm, c->side); what = "ncclRecv"; }
+    if (r_hi && first == ncclSuccess) { first = r->Recv(d_recv_hi, n_recv_hi, ncclFloat64, c->rank + 1, c->comm, c->side); what = "ncclRecv"; }
+    if (s_lo && first == ncclSuccess) { first = r->Send(d_send_lo, n_send_lo, ncclFloat64, c->rank - 1, c->comm, c->side); what = "ncclSend"; }
+    if (s_hi && first == ncclSuccess) { first = r->Send(d_send_hi, n_send_hi, ncclFloat64, c->rank + 1, c->comm, c->side); what = "ncclSend"; }
+    const ncclResult_t ge = r->GroupEnd();
+    if (first != ncclSuccess) return comm_nccl_error(c, what, first);
+    if (ge != ncclSuccess) return comm_nccl_error(c, "ncclGroupEnd", ge);
     return comm_end(c);
 }
 

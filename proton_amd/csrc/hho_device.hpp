@@ -981,9 +981,15 @@ __device__ __forceinline__ uint32_t sel4u(uint32_t v0, uint32_t v1, uint32_t v2,
 //             condensed right-hand side are the only output -- or, given the face unknowns, the recovered cell unknowns.
 enum { MODE_LC = 0, MODE_SPLIT = 1, MODE_COND = 2 };
 // hho_pre.hpp: the head of one cell in the registers of the calling lane, its record to `out` (pairs 16 doubles apart)
+struct PreArgs {
+    const QuadTables *tab;
+    const double *points;
+    const uint32_t *ptids;
+    size_t first, n;           // cells first .. first+n-1; record of cell first+i: tile i / 8, slot i % 8 (see the kernel)
+    double *pre;
+};
 template <class C>
-__device__ __forceinline__ void cell_pre_record(const QuadTables *__restrict__ tab, const double *__restrict__ points,
-                                                const uint32_t *__restrict__ ptids, size_t cell, double *out);
+__device__ __forceinline__ void cell_pre_record(const PreArgs &a, size_t cell, double *out);
 template <class C, int MODE>
 __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::WAVES) void hho_local_ops_kernel(LocalOpsArgs a)
 {
@@ -997,12 +1003,61 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
     static_assert(RBS <= G && NF <= G, "one lane per row in the factorizations");
     static_assert(C::NQ > 0, "empty quadrature rule (the rules[8] hole)");
 
+#if PA_SELF_PRE
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const QuadTables *__restrict__ tab = a.tab;
+    typedef typename C::Pre PRE;
+    // Blocks b and b + 8 share an XCD (round-robin dispatch; a speed assumption only): give the blocks of an XCD
+    // consecutive cells, so that the 8 cells of a record tile, and the lines of lc they share, meet in one L2.
+    const size_t lblock = (PA_XCD_MAP && gridDim.x % 8 == 0) ? (size_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (size_t)blockIdx.x;
+    const size_t stride = (size_t)gridDim.x * C::CPW;
+    // Cfg::SELF_PRE: the wavefront's own ring of 64 records; pass ib of a batch reads the slots ib CPW + g
+    constexpr bool SELF = C::SELF_PRE;
+    constexpr int SELF_IT = C::SELF_IT;
+    double *ring = SELF ? a.pre_ring + (size_t)blockIdx.x * (size_t)(64 * PRE::NPRE) : nullptr;
+#ifdef PA_STAGE_CLOCK
+    long long tk_sum[PA_NSTAGE] = {0}, tk_last = clock64();
+#endif
+    // Cfg::SELF_PRE: an outer loop over batches of SELF_IT passes -- the heads of the batch's 64 cells first (the thread-per-cell code
+    // of hho_pre.hpp, which needs every register the kernel has), then the per-lane bookkeeping of the cooperative passes, re-derived
+    // per batch from an opaque lane index so that nothing of it is live across the production, then the passes.  Otherwise one batch.
+    size_t base = lblock * C::CPW;
+    // the FIRST batch of a wavefront is shorter by a pseudo-random number of passes: the wavefronts of a compute unit then stop for their
+    // production at different times, next to the others' passes (all at once they are the pre-pass again: the whole chip writing records)
+    int nb = SELF ? SELF_IT - (int)(((uint32_t)blockIdx.x * 2654435761u) >> 8) % SELF_IT : 1;
+    while (base < a.n) {
+    int lane = threadIdx.x;
+    if (SELF) {
+        // lane j's cell is the one group j % CPW of pass j / CPW of the batch will work on.  Every record of the previous batch has
+        // been consumed (the last one was deposited in region P a pass ago), so the ring is free.  Own stores, then own loads:
+        // s_waitcnt vmcnt(0) orders them (the vector L1 is write-through and the lines belong to this compute unit alone).
+        PA_MARK("SELFPRE");
+        const size_t idx = base + (size_t)(lane / C::CPW) * stride + (size_t)(lane % C::CPW);
+        if (idx < a.n && lane / C::CPW < nb)
+            cell_pre_record<C>(PreArgs{tab, a.points, a.ptids, 0, 0, nullptr}, a.first + idx,
+                               ring + ((uint32_t)lane >> 3) * (uint32_t)(PRE::NP2 * 16) + ((uint32_t)lane & 7u) * 2u);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(lane) : : "memory");
+    }
+    const int g = lane / G, l0 = lane % G;
+    const int l = l0;
+    double *S = smem + g * C::LDS_PER_CELL;
+#else
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     const int g = lane / G, l0 = lane % G;
     const int l = l0;
     double *S = smem + g * C::LDS_PER_CELL;
     const QuadTables *__restrict__ tab = a.tab;
+    typedef typename C::Pre PRE;
+    // Blocks b and b + 8 share an XCD (round-robin dispatch; a speed assumption only): give the blocks of an XCD
+    // consecutive cells, so that the 8 cells of a record tile, and the lines of lc they share, meet in one L2.
+    const size_t lblock = (PA_XCD_MAP && gridDim.x % 8 == 0) ? (size_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (size_t)blockIdx.x;
+    const size_t stride = (size_t)gridDim.x * C::CPW;
+    constexpr bool SELF = false;
+#ifdef PA_STAGE_CLOCK
+    long long tk_sum[PA_NSTAGE] = {0}, tk_last = clock64();
+#endif
+#endif
     // constant face tables, kept in scalar registers
     FaceTables ft;
 #pragma unroll
@@ -1179,7 +1234,6 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
     }
 
     // pairs of the cell's pre-pass record this lane moves to LDS, and where their two doubles go
-    typedef typename C::Pre PRE;
     int pre_dst[C::PLC][2];
 #pragma unroll
     for (int t = 0; t < C::PLC; ++t) {
@@ -1212,14 +1266,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
     // registers while S1-S6 run, and go to region P when S6 is done with it -- before the stores of S8 are
     // issued, so that no load ever queues behind them (vector memory operations complete in order).
     double2 rec[C::PLC];
-    // Blocks b and b + 8 share an XCD (round-robin dispatch; a speed assumption only): give the blocks of an XCD
-    // consecutive cells, so that the 8 cells of a record tile, and the lines of lc they share, meet in one L2.
-    const size_t lblock = (PA_XCD_MAP && gridDim.x % 8 == 0) ? (size_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (size_t)blockIdx.x;
-    const size_t stride = (size_t)gridDim.x * C::CPW;
-    // Cfg::SELF_PRE: the wavefront's own ring of 64 records; pass `it` of the block reads the slots (it mod SELF_IT) CPW + g
-    constexpr bool SELF = C::SELF_PRE;
-    constexpr int SELF_IT = C::SELF_IT;
-    double *ring = SELF ? a.pre_ring + (size_t)blockIdx.x * (size_t)(64 * PRE::NPRE) : nullptr;
+#if PA_SELF_PRE
     auto rec_issue_slot = [&](int ib) {
         const uint32_t s = (uint32_t)(ib * C::CPW + g);
         const double *pc = ring + (s >> 3) * (uint32_t)(PRE::NP2 * 16) + (s & 7u) * 2u;
@@ -1229,6 +1276,9 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             rec[t] = *reinterpret_cast<const double2 *>(pc + 16 * (e2 < PRE::NP2 ? e2 : 0));
         }
     };
+#else
+    auto rec_issue_slot = [&](int) {};
+#endif
     auto rec_issue = [&](size_t b) {
         // records lie in tiles of 8 cells, [tile][pair][cell % 8] (hho_pre.hpp): the pairs of one record are 128 bytes apart
         // (b is a multiple of the CPW cells of a wavefront, CPW divides 8: the wavefront's cells share a tile, whose address is
@@ -1260,34 +1310,20 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
             for (int e = l; e < C::LGR * LD; e += G) S[C::oLG + e] = 0.0;
             wave_sync();
         }
-        if (!SELF) {
-            rec_issue(lblock * C::CPW);
-            rec_deposit();
-            wave_sync();
-        }
+        if (!SELF) rec_issue(lblock * C::CPW);
+        else rec_issue_slot(0);
+        rec_deposit();
+        wave_sync();
     }
 
-#ifdef PA_STAGE_CLOCK
-    long long tk_sum[PA_NSTAGE] = {0}, tk_last = clock64();
+#if PA_SELF_PRE
+    const int nbc = nb;
+    nb = SELF_IT;
+    for (int ib = 0; (!SELF || ib < nbc) && base < a.n; base += stride, ++ib) {
+#else
+    constexpr int ib = 0, nbc = 1;
+    for (size_t base = lblock * C::CPW; base < a.n; base += stride) {
 #endif
-    int it = 0;
-    for (size_t base = lblock * C::CPW; base < a.n; base += stride, ++it) {
-        const int ib = SELF ? it % SELF_IT : 0;
-        if (SELF && ib == 0) {
-            // the heads of the next 64 cells of this wavefront, one per lane: lane j's cell is the one group j % CPW of pass
-            // it + j / CPW will work on.  Every record of the previous batch has been consumed (the last one was deposited in
-            // region P a pass ago), so the ring is free.  Own stores, then own loads: s_waitcnt vmcnt(0) orders them (the vector
-            // L1 is write-through and the lines belong to this compute unit alone).
-            PA_MARK("SELFPRE");
-            const size_t idx = base + (size_t)(lane / C::CPW) * stride + (size_t)(lane % C::CPW);
-            if (idx < a.n)
-                cell_pre_record<C>(tab, a.points, a.ptids, a.first + idx,
-                                   ring + ((uint32_t)lane >> 3) * (uint32_t)(PRE::NP2 * 16) + ((uint32_t)lane & 7u) * 2u);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            rec_issue_slot(0);
-            rec_deposit();
-            wave_sync();
-        }
         // Re-derive the lane index opaquely per cell: otherwise LICM hoists the index computations
         // of every stage out of the cell loop and the kernel spills.
         int l = l0;
@@ -1325,7 +1361,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         if (C::USE_PRE) {
             // the per-cell head comes from the pre-pass; its record is in region P already (prefetched)
             if (!SELF) rec_issue(base + stride);
-            else if (ib + 1 < SELF_IT) rec_issue_slot(ib + 1);
+            else if (ib + 1 < nbc) rec_issue_slot(ib + 1);
             const double2 bb = lds_pair(S + C::oSU + 4), ib = lds_pair(S + C::oSU + 6);
             barx = bb.x; bary = bb.y; ih = ib.x; bad_pre = (int)ib.y;
         } else {
@@ -1946,7 +1982,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                 t11s[gi] = su * su;
             }
         }
-        if (C::USE_PRE && (!COND || C::COND_OWN_P) && (!SELF || ib + 1 < SELF_IT)) rec_deposit();
+        if (C::USE_PRE && (!COND || C::COND_OWN_P) && (!SELF || ib + 1 < nbc)) rec_deposit();
         // condensed mode: the cell's right-hand side (lanes < CBS) and, for the recovery, its face unknowns (lanes < NF),
         // one value per lane, in flight during the product
         double fT_l = 0.0, uF_l = 0.0;
@@ -2317,7 +2353,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
                     if (valid && a.uT != nullptr && l < CBS) a.uT[rel(CBS) + l] = t;
                 }
                 wave_sync();      // every read of the image is done
-                if (C::USE_PRE && !C::COND_OWN_P && (!SELF || ib + 1 < SELF_IT)) { rec_deposit(); wave_sync(); }      // the next cell's record, into its place in region P
+                if (C::USE_PRE && !C::COND_OWN_P && (!SELF || ib + 1 < nbc)) { rec_deposit(); wave_sync(); }      // the next cell's record, into its place in region P
             } else if (DIRECT) {
                 wave_sync();      // the next cell's tables overwrite Z
             } else if (EARLY_OUT) {
@@ -2422,6 +2458,9 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         if (valid && a.info != nullptr && l == 0) a.info[rel(1)] = bad;
         PA_TICK(10);
     }
+#if PA_SELF_PRE
+    }
+#endif
 #ifdef PA_STAGE_CLOCK
     if (a.dbg != nullptr && lane == 0)
         for (int i = 0; i < PA_NSTAGE; ++i) a.dbg[(size_t)blockIdx.x * PA_NSTAGE + i] = tk_sum[i];

@@ -19,6 +19,12 @@
     (int)(pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, (pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::MS + 1 <= G ? G : 64), 1>::LDS_DOUBLES * sizeof(double)), \
     "hho_condensed_ops<cd=" PA_STR(PA_CD) ",fd=" PA_STR(PA_FD) ",quad=" PA_STR(PA_QUAD) ",stab=" #STAB ",G=" #G ">", \
     pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, (pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::MS + 1 <= G ? G : 64), 1>::WAVES
+// the thread-per-cell kernel of the small pairs (msize <= 9: (0,0), (1,0), (0,1)); instantiated for those only
+#if (PA_CD + 2) * (PA_CD + 1) / 2 + 4 * (PA_FD + 1) <= 9
+#define PA_SMALL_OF(STAB, G) &pa::launch_small_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>>
+#else
+#define PA_SMALL_OF(STAB, G) nullptr
+#endif
 #define PA_ENTRY(STAB, G, COND)                                                                    \
     {PA_CD, PA_FD, PA_QUAD, STAB, G, &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, pa::MODE_LC>, \
      &pa::launch_local_ops<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>, pa::MODE_SPLIT>,                 \
@@ -27,7 +33,9 @@
      "hho_local_ops<cd=" PA_STR(PA_CD) ",fd=" PA_STR(PA_FD) ",quad=" PA_STR(PA_QUAD) ",stab=" #STAB ",G=" #G ">",                \
      pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::WAVES,                                                \
      pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::USE_PRE ? &pa::launch_pre<pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>> : nullptr, \
-     pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::Pre::NPRE, pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::SELF_PRE ? 1 : 0, COND}
+     pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::Pre::NPRE,                                            \
+     PA_SMALL_OF(STAB, G), "hho_small_ops<cd=" PA_STR(PA_CD) ",fd=" PA_STR(PA_FD) ",quad=" PA_STR(PA_QUAD) ",stab=" #STAB ">", \
+     pa::Cfg<PA_CD, PA_FD, PA_QUAD, STAB, G>::SELF_PRE ? 1 : 0, COND}
 #define PA_ENTRIES_G(G) PA_ENTRY(0, G, PA_COND_NONE), PA_ENTRY(1, G, PA_COND_OF(1, G)), PA_ENTRY(2, G, PA_COND_OF(2, G))
 
 static const pa::KernelEntry k_entries[] = {

@@ -3,11 +3,13 @@
 #include <hip/hip_runtime.h>
 #include "hho_device.hpp"
 #include "hho_pre.hpp"
+#include "hho_small.hpp"
 
 namespace pa {
 
 typedef hipError_t (*local_ops_launcher)(const LocalOpsArgs &, int grid, hipStream_t);
 typedef hipError_t (*pre_launcher)(const PreArgs &, hipStream_t);
+typedef hipError_t (*small_launcher)(const SmallOpsArgs &, hipStream_t);
 
 struct KernelEntry {
     int cd, fd, quad, stab, lanes_per_cell;
@@ -19,6 +21,8 @@ struct KernelEntry {
     int waves_per_simd;        // the occupancy the instance is tuned for (Cfg::WAVES): the grid does not exceed it
     pre_launcher launch_pre;   // the one-thread-per-cell pre-pass the kernel consumes (nullptr: all-in-one kernel)
     int pre_doubles;           // doubles per cell of its record (Cfg::Pre::NPRE)
+    small_launcher launch_small;   // msize <= 9: the thread-per-cell kernel of hho_small.hpp (lc + info only; nullptr otherwise)
+    const char *name_small;
     int self_pre;              // Cfg::SELF_PRE: the cooperative kernel forms the records itself, into one ring of 64 per block (no pre-pass launch)
     // condensed mode (static condensation fused behind the product; nullptr without a stabilization: A_TT singular)
     local_ops_launcher launch_cond;

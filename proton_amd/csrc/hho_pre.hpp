@@ -21,13 +21,6 @@
 #endif
 namespace pa {
 
-struct PreArgs {
-    const QuadTables *tab;
-    const double *points;
-    const uint32_t *ptids;
-    size_t first, n;           // cells first .. first+n-1; record of cell first+i: tile i / 8, slot i % 8 (see the kernel)
-    double *pre;
-};
 
 // The head of ONE cell, all of it in the registers of the calling lane; `out` = where pair 0 of the cell's record goes, the
 // other 16-byte pairs follow at a stride of 16 doubles (the tiles of 8 records described below).  Called by the pre-pass
@@ -35,12 +28,11 @@ struct PreArgs {
 // wavefront stops every 64 / CPW passes and forms the heads of the 64 cells it will visit next, one per lane, into a ring of 64
 // records of its own (hho_device.hpp).
 template <class C>
-__device__ __forceinline__ void cell_pre_record(const QuadTables *__restrict__ tab, const double *__restrict__ points,
-                                                const uint32_t *__restrict__ ptids, size_t cell, double *out)
+__device__ __forceinline__ void cell_pre_record(const PreArgs &a, size_t cell, double *out)
 {
     constexpr int RD = C::RD, NR = C::NR, NPW = C::NPW, NMOM = C::NMOM;
     typedef typename C::Pre PL;
-    struct { const double *points; const uint32_t *ptids; } a = {points, ptids};
+    const QuadTables *__restrict__ tab = a.tab;
 
     // ---- geometry (the same expressions as S0 of the cooperative kernel)
     const uint4 idv = *reinterpret_cast<const uint4 *>(a.ptids + 4 * cell);
@@ -267,7 +259,7 @@ __global__ __launch_bounds__(64, PA_PRE_WAVES) void hho_cell_pre_kernel(PreArgs 
     typedef typename C::Pre PL;
     const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= a.n) return;
-    cell_pre_record<C>(a.tab, a.points, a.ptids, a.first + i, a.pre + (((i >> 3) * (size_t)PL::NP2) * 8 + (i & 7)) * 2);
+    cell_pre_record<C>(a, a.first + i, a.pre + (((i >> 3) * (size_t)PL::NP2) * 8 + (i & 7)) * 2);
 }
 
 }  // namespace pa

@@ -270,14 +270,17 @@ __global__ __launch_bounds__(RB) void cg_direction_rows_kernel(size_t n, double 
     d[i] = (precond ? iA[i] * r[i] : r[i]) + beta * d[i];
 }
 
-// status: 0 ok, 1 transport callback failed, 2 a row reads a column beyond its two neighbours' ranges cannot be checked here (the
-// window is what the rows read; the neighbours answer with what they can give)
+// status: 0 ok; 1 a transport callback failed on THIS rank; 2 this rank's rows read a column no neighbour range covers (or, without a
+// transport, beyond its own range); 3 another rank failed (its status says why); 4 a HIP error on this rank.
+// EVERY exit is collective: a rank that fails locally -- a callback, a HIP call, the range check -- does not leave the others inside a
+// reduction or a neighbour exchange.  Its failure is a flag that rides on the next all-reduce (an extra addend behind the dot products),
+// every rank sees the sum and all of them leave together, at the same point.  (What cannot be covered: the all-reduce itself failing
+// on one rank only -- then there is nothing left to tell the others with.)
 hipError_t conjugated_gradient_rows(hipStream_t stream, const CgTransport *tp, int64_t row_begin, int64_t row_end, const int64_t *rowptr,
                                     const int32_t *colind, const double *values, const double *b, double *x,
                                     double convergence_threshold, double divergence_threshold, size_t max_iter, int precond,
                                     int *exit_reason, size_t *iterations, double *relative_residual, int *transport_status)
 {
-    hipError_t e = hipSuccess;
     const size_t n = (size_t)(row_end - row_begin);
     double *r = nullptr, *dwin = nullptr, *y = nullptr, *iA = nullptr, *pa_ = nullptr, *pb_ = nullptr, *sums = nullptr;
     int *mm = nullptr;
@@ -290,52 +293,73 @@ hipError_t conjugated_gradient_rows(hipStream_t stream, const CgTransport *tp, i
         (void)hipFree(sums); (void)hipFree(mm);
     };
     if (transport_status) *transport_status = 0;
-#define CG_TRY(call) do { e = (call); if (e != hipSuccess) { cleanup(); return e; } } while (0)
-#define CG_TP(call) do { if ((call) != 0) { if (transport_status) *transport_status = 1; cleanup(); return hipSuccess; } } while (0)
+    int fail = 0;                          // this rank's status (see above); 0 while everything went well
+    hipError_t herr = hipSuccess;
+    auto hip_ok = [&](hipError_t e) -> bool { if (e != hipSuccess && !fail) { fail = 4; herr = e; } return e == hipSuccess; };
+    auto leave = [&](int status) -> hipError_t {
+        if (transport_status) *transport_status = status;
+        cleanup();
+        return status == 4 ? herr : hipSuccess;
+    };
+    // all ranks agree on whether anybody failed: the flag summed over the ranks (one rank: the flag itself)
+    auto agree = [&]() -> int {
+        double f = fail ? 1.0 : 0.0;
+        if (tp && tp->allreduce_sum(tp->user, &f, 1) != 0) return fail ? fail : 1;
+        return f > 0.0 ? (fail ? fail : 3) : 0;
+    };
     // the columns the local rows read
     int64_t need_lo = 0, need_hi = 0;
     {
         int64_t nnz = 0;
         if (n) {
-            int64_t ends[2];
-            CG_TRY(hipMemcpyAsync(&ends[0], rowptr, 8, hipMemcpyDeviceToHost, stream));
-            CG_TRY(hipMemcpyAsync(&ends[1], rowptr + n, 8, hipMemcpyDeviceToHost, stream));
-            CG_TRY(hipStreamSynchronize(stream));
-            nnz = ends[1] - ends[0];
+            int64_t ends[2] = {0, 0};
+            if (hip_ok(hipMemcpyAsync(&ends[0], rowptr, 8, hipMemcpyDeviceToHost, stream)) &&
+                hip_ok(hipMemcpyAsync(&ends[1], rowptr + n, 8, hipMemcpyDeviceToHost, stream)) && hip_ok(hipStreamSynchronize(stream)))
+                nnz = ends[1] - ends[0];
         }
         int h[2] = {0x7fffffff, -1};
-        CG_TRY(hipMalloc((void **)&mm, 8));
-        CG_TRY(hipMemcpyAsync(mm, h, 8, hipMemcpyHostToDevice, stream));
-        if (nnz > 0) hipLaunchKernelGGL(cg_col_range_kernel, dim3((unsigned)((nnz + RB - 1) / RB)), dim3(RB), 0, stream, (size_t)nnz, colind, mm);
-        CG_TRY(hipMemcpyAsync(h, mm, 8, hipMemcpyDeviceToHost, stream));
-        CG_TRY(hipStreamSynchronize(stream));
-        if (nnz > 0) {
-            need_lo = h[0] < row_begin ? row_begin - h[0] : 0;
-            need_hi = (int64_t)h[1] + 1 > row_end ? (int64_t)h[1] + 1 - row_end : 0;
+        if (!fail && hip_ok(hipMalloc((void **)&mm, 8)) && hip_ok(hipMemcpyAsync(mm, h, 8, hipMemcpyHostToDevice, stream))) {
+            if (nnz > 0) hipLaunchKernelGGL(cg_col_range_kernel, dim3((unsigned)((nnz + RB - 1) / RB)), dim3(RB), 0, stream, (size_t)nnz, colind, mm);
+            if (hip_ok(hipMemcpyAsync(h, mm, 8, hipMemcpyDeviceToHost, stream)) && hip_ok(hipStreamSynchronize(stream)) && nnz > 0) {
+                need_lo = h[0] < row_begin ? row_begin - h[0] : 0;
+                need_hi = (int64_t)h[1] + 1 > row_end ? (int64_t)h[1] + 1 - row_end : 0;
+            }
         }
     }
     int64_t give_lo = 0, give_hi = 0;      // what the neighbours below / above read of MY range (its first / last entries)
-    if (tp) CG_TP(tp->neighbour_counts(tp->user, need_lo, need_hi, &give_lo, &give_hi));
-    else if (need_lo || need_hi) { if (transport_status) *transport_status = 2; cleanup(); return hipSuccess; }
-    if (give_lo > (int64_t)n || give_hi > (int64_t)n) { if (transport_status) *transport_status = 2; cleanup(); return hipSuccess; }
+    if (tp) {
+        // (a rank that already failed still answers its neighbours -- with what it needs, zero -- so that they are not left waiting)
+        if (tp->neighbour_counts(tp->user, fail ? 0 : need_lo, fail ? 0 : need_hi, &give_lo, &give_hi) != 0 && !fail) fail = 1;
+    } else if (need_lo || need_hi) fail = 2;
+    if (!fail && (give_lo > (int64_t)n || give_hi > (int64_t)n)) fail = 2;
     const size_t nwin = n + (size_t)need_lo + (size_t)need_hi;
-    CG_TRY(hipMalloc((void **)&r, nn * 8)); CG_TRY(hipMalloc((void **)&dwin, (nwin ? nwin : 1) * 8)); CG_TRY(hipMalloc((void **)&y, nn * 8));
-    CG_TRY(hipMalloc((void **)&iA, nn * 8)); CG_TRY(hipMalloc((void **)&pa_, nparts * 8)); CG_TRY(hipMalloc((void **)&pb_, nparts * 8));
-    CG_TRY(hipMalloc((void **)&sums, 16));
-    CG_TRY(hipMemsetAsync(dwin, 0, (nwin ? nwin : 1) * 8, stream));
+    if (!fail) {
+        (void)(hip_ok(hipMalloc((void **)&r, nn * 8)) && hip_ok(hipMalloc((void **)&dwin, (nwin ? nwin : 1) * 8)) && hip_ok(hipMalloc((void **)&y, nn * 8)) &&
+               hip_ok(hipMalloc((void **)&iA, nn * 8)) && hip_ok(hipMalloc((void **)&pa_, nparts * 8)) && hip_ok(hipMalloc((void **)&pb_, nparts * 8)) &&
+               hip_ok(hipMalloc((void **)&sums, 16)) && hip_ok(hipMemsetAsync(dwin, 0, (nwin ? nwin : 1) * 8, stream)));
+    }
+    {
+        const int st = agree();            // nobody starts iterating unless everybody can
+        if (st) return leave(st);
+    }
     double *d = dwin + need_lo;            // the owned part of the window
-    double hs[2];
-    auto reduce2 = [&](size_t np, const double *pa2, const double *pb2, int nvals) -> int {      // local sums -> host -> ranks
-        hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(RB), 0, stream, np, pa2, pb2, sums);
-        if (hipMemcpyAsync(hs, sums, 16, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
-        if (hipStreamSynchronize(stream) != hipSuccess) return -1;
-        if (tp && tp->allreduce_sum(tp->user, hs, nvals) != 0) return 1;
-        return 0;
+    double hs[3];
+    // local sums -> host -> ranks, the failure flag behind them.  Returns 0, or the status all ranks leave with.
+    auto reduce2 = [&](size_t np, const double *pa2, const double *pb2, int nvals) -> int {
+        hs[0] = hs[1] = 0.0;
+        if (!fail) {
+            hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(RB), 0, stream, np, pa2, pb2, sums);
+            (void)(hip_ok(hipMemcpyAsync(hs, sums, 16, hipMemcpyDeviceToHost, stream)) && hip_ok(hipStreamSynchronize(stream)));
+        }
+        hs[nvals] = fail ? 1.0 : 0.0;
+        if (tp && tp->allreduce_sum(tp->user, hs, nvals + 1) != 0) return fail ? fail : 1;
+        return hs[nvals] > 0.0 ? (fail ? fail : 3) : 0;
     };
-    auto refresh = [&]() -> int {          // the two ends of the window from the neighbours, my ends to them
-        if (!tp) return 0;
-        return tp->halo(tp->user, d, (size_t)give_lo, d + (n - (size_t)give_hi), (size_t)give_hi, dwin, (size_t)need_lo, d + n, (size_t)need_hi,
-                        (void *)stream);
+    auto refresh = [&]() {                 // the two ends of the window from the neighbours, my ends to them
+        if (!tp || fail) return;           // (a failed rank does not post: it tells the others at the reduction that follows the product)
+        if (tp->halo(tp->user, d, (size_t)give_lo, d + (n - (size_t)give_hi), (size_t)give_hi, dwin, (size_t)need_lo, d + n, (size_t)need_hi,
+                     (void *)stream) != 0)
+            fail = 1;
     };
     size_t iter = 0;
     int reason = 2;
@@ -345,24 +369,22 @@ hipError_t conjugated_gradient_rows(hipStream_t stream, const CgTransport *tp, i
         // r = b, d = M^-1 r (x = 0), partials of r.r and r.M^-1 r       solver_cg.hpp:73-84
         hipLaunchKernelGGL(cg_init_kernel, dim3(gv), dim3(RB), 0, stream, n, b, iA, precond, x, r, d, pa_, pb_);
         int st = reduce2(gv, pa_, pb_, 2);
-        if (st < 0) { CG_TRY(hipErrorUnknown); }
-        if (st > 0) CG_TP(1);
+        if (st) return leave(st);
         const double nr0 = sqrt(hs[0]);
         double rho = hs[1];
         if (!(nr0 > 0.0)) { reason = 0; }
         else
             for (;;) {
-                CG_TP(refresh());
-                hipLaunchKernelGGL(cg_spmv_rows_kernel, dim3(gs), dim3(RB), 0, stream, n, row_begin - need_lo, (size_t)need_lo, rowptr, colind,
-                                   values, dwin, y, pa_);                                                            // :99
+                refresh();
+                if (!fail)
+                    hipLaunchKernelGGL(cg_spmv_rows_kernel, dim3(gs), dim3(RB), 0, stream, n, row_begin - need_lo, (size_t)need_lo, rowptr, colind,
+                                       values, dwin, y, pa_);                                                        // :99
                 st = reduce2(gs, pa_, (const double *)nullptr, 1);
-                if (st < 0) { CG_TRY(hipErrorUnknown); }
-                if (st > 0) CG_TP(1);
+                if (st) return leave(st);
                 const double alpha = rho / hs[0];                                                                    // :101-102
                 hipLaunchKernelGGL(cg_update_rows_kernel, dim3(gv), dim3(RB), 0, stream, n, alpha, iA, precond, d, y, x, r, pa_, pb_);   // :103-105
                 st = reduce2(gv, pa_, pb_, 2);
-                if (st < 0) { CG_TRY(hipErrorUnknown); }
-                if (st > 0) CG_TP(1);
+                if (st) return leave(st);
                 rr = sqrt(hs[0]) / nr0;
                 if (rr < convergence_threshold) { reason = 0; break; }      // :107-110
                 if (iter > max_iter) { reason = 2; break; }                  // :112-115
@@ -374,10 +396,11 @@ hipError_t conjugated_gradient_rows(hipStream_t stream, const CgTransport *tp, i
                 iter++;
             }
     }
-    CG_TRY(hipGetLastError());
-    CG_TRY(hipStreamSynchronize(stream));
-#undef CG_TRY
-#undef CG_TP
+    (void)(hip_ok(hipGetLastError()) && hip_ok(hipStreamSynchronize(stream)));
+    {
+        const int st = agree();            // a rank whose last launches failed says so before anybody reports success
+        if (st) return leave(st);
+    }
     cleanup();
     if (exit_reason) *exit_reason = reason;
     if (iterations) *iterations = iter;

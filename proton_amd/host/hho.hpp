@@ -559,7 +559,10 @@ class batch_cache {
     // proton_amd::invalidate(msh).
     void ensure_mesh(const Mesh &m, size_t pos = 0)
     {
-        const bool sweep_continues = pos > last_pos_;
+        // (>=: the reference's loop body calls make_hho_laplacian, the stabilization and make_rhs on the SAME cell -- with >
+        // the second and third call of every cell re-hashed every point: O(cells x points) per sweep; pos 0 -- the first cell, and
+        // every call that is not tied to a cell -- always re-hashes)
+        const bool sweep_continues = pos > 0 && pos >= last_pos_;
         last_pos_ = pos;
         if (sweep_continues ? !dev_mesh_.same_object(m) : !dev_mesh_.matches(m)) {
             batches_.clear(); qpoints_.clear(); face_qpoints_.clear(); face_samples_.clear();

@@ -4,8 +4,10 @@
 //   2. a mesh edited in place between two sweeps (one node displaced): the operators of the new geometry are served;
 //   3. make_hho_fancy_stabilization honours its `reconstruction` argument: the cell's own operator is accepted, any
 //      other matrix is refused (hho.hpp:155-159, 184-190);
-//   4. two proton_amd::device objects in one process, selected with device_scope, hold two different meshes side by side.
+//   4. two proton_amd::device objects in one process, selected with device_scope, hold two different meshes side by side;
+//   5. the per-cell loop body over 65 536 cells stays linear in the number of cells (time bound).
 // Prints "check <n> ok" per item; exit code 0 iff all pass.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -104,6 +106,24 @@ int main()
         auto ra = make_hho_laplacian(coarse, coarse.cells[5], hdi).second;
         auto rb = make_hho_laplacian(fine, fine.cells[5], hdi).second;
         report(4, max_abs_diff(da, ra) == 0 && max_abs_diff(db, rb) == 0 && max_abs_diff(da2, ra) == 0 && max_abs_diff(ra, rb) > 1e-6);
+    }
+
+    // 5. the reference's loop body (make_hho_laplacian, stabilization, make_rhs on the same cell) over a 256 x 256 mesh through the
+    //    per-cell API: the mesh's coordinates are re-hashed once per sweep, not once per call (O(cells x points))
+    {
+        mesh_type big = make_mesh(256);
+        auto rhs_fun = [](const mesh_type::point_type &pt) -> T { return std::sin(M_PI * pt.x()) * std::sin(M_PI * pt.y()); };
+        const auto t0 = std::chrono::steady_clock::now();
+        T acc = 0;
+        for (auto &cl : big.cells) {
+            auto gr = make_hho_laplacian(big, cl, hdi);
+            auto stab = make_hho_fancy_stabilization(big, cl, gr.first, hdi);
+            auto f = make_rhs(big, cl, hdi.cell_degree(), rhs_fun);
+            acc += gr.second(0, 0) + stab(1, 1) + f(0);
+        }
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("per-cell sweep of %zu cells: %.2f s (checksum %.6e)\n", big.cells.size(), sec, acc);
+        report(5, std::isfinite(acc) && sec < 20.0);
     }
     return failures ? 1 : 0;
 }

@@ -51,3 +51,21 @@ def test_bench_line_carries_the_contract_fields():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "cells/s" and cb["sample"]
     assert d["gpu_over_cpu"] > 10.0                                     # the north star's floor
+    # counters are never replayed across builds: the line names its build, and `traffic` is that build's or null with the reason
+    from proton_amd import _build
+    assert d["build_stamp"] == _build.build_stamp() and ro["traffic_source"]
+    assert ro["traffic"] is None or "counters of this build" in ro["traffic_source"]
+
+
+@pytest.mark.gpu
+def test_bench_mode_A_reports_the_matrix_assembly_span():
+    """--mode A: operators + rhs + assembler<Mesh>'s own system directly in CSR, next to the CPU restatement's "Matrix assembly" span"""
+    r = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--settle-ms", "20", "--workload", "quad256_k1_fan", "--mode", "A",
+              "--cpu-sample-rows", "8"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["mode"] == "A" and d["stage_ms"]["fill"] > 0 and d["stage_ms"]["ops"] > 0
+    ma = d["matrix_assembly"]
+    assert ma["cpu_one_core"] > 0 and ma["gpu_over_cpu_one_core"] > 10.0 and abs(ma["value"] - d["value"]) < 1e-9 * d["value"]
+    pk = d["roofline"]["per_kernel"]
+    assert pk["fill"]["bytes"] > 0 and 0 < pk["fill"]["frac"] < 1

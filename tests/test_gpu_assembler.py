@@ -141,6 +141,45 @@ def test_device_csr_equals_set_from_triplets(asm, N, cd, fd):
     assert int(rowptr[-1]) == ref.nnz
 
 
+@pytest.mark.parametrize("N,cd,fd", [(6, 2, 1), (9, 3, 2), (5, 0, 1), (7, 4, 3), (8, 1, 1), (6, 0, 0), (33, 3, 2)])
+def test_direct_assembler_csr_equals_set_from_triplets(asm, N, cd, fd):
+    """pa_assembler_csr_pattern / _fill -- assembler<Mesh>'s own system (cell + face unknowns, hho.hpp:298-335, 344-406,
+    451-455) built from the face adjacency, no triplets, no sort -- is bit for bit the CSR pa_csr_from_triplets makes of
+    pa_triplets_batch: row pointers, column indices, values; the right-hand side is the scatter-add of the triplet path's
+    per-row sums in cell order (hho.hpp:401, 405)."""
+    import torch
+    lc, rhs, g, r, c, v, rr, rv = gpu_assembly(asm, N, cd, fd)
+    info = asm.assembler_info(cd, fd)
+    rowptr, colind, values = asm.csr_from_triplets(r, c, v, info.system_size)
+    rp2, ci2 = asm.assembler_csr_pattern(cd, fd)
+    va2, RHS2 = asm.assembler_csr_fill(cd, fd, lc, rhs, g)
+    asm.synchronize()
+    assert rp2.numel() == info.system_size + 1 and int(rp2[-1]) == int(rowptr[-1]) == ci2.numel()
+    assert torch.equal(rp2, rowptr) and torch.equal(ci2, colind)
+    assert torch.equal(va2, values)
+    RR, RV = rr.cpu().numpy().ravel(), rv.cpu().numpy().ravel()
+    want = np.zeros(info.system_size)
+    keep = RR >= 0
+    np.add.at(want, RR[keep], RV[keep])
+    assert np.array_equal(RHS2.cpu().numpy(), want)
+    # homogeneous data, no cell right-hand side: the values are the same, the right-hand side is zero
+    va3, RHS3 = asm.assembler_csr_fill(cd, fd, lc)
+    asm.synchronize()
+    assert torch.equal(va3, values) and float(RHS3.abs().max()) == 0.0
+
+
+def test_direct_assembler_csr_refuses_a_slab(asm):
+    """a slab of a partitioned mesh owns a block of FACE rows (pa_condensed_*): the cell + face system is whole-mesh only"""
+    import ctypes as C
+    import proton_amd as pa
+    asm.generate_mesh(8, 8, rows=(2, 5))
+    di, _ = pa.capi.degree_info(2, 1)
+    out = pa.capi.AssemblerCsrInfo()
+    assert pa.capi.lib().pa_assembler_csr_query(asm.ctx.h, di, C.byref(out)) == 1
+    asm.generate_mesh(8, 8)
+    assert pa.capi.lib().pa_assembler_csr_query(asm.ctx.h, di, C.byref(out)) == 0 and out.nrows == 6 * 64 + 2 * (2 * 8 * 9 - 32)
+
+
 def test_device_csr_edge_cases(asm):
     """empty input, all slots dropped, long runs of duplicates summed in push order, sizes around the scan tile"""
     import torch

@@ -29,8 +29,10 @@ def _slab_system(N, cd, fd, rows, halo):
 class ThreadTransport:
     """pa_cg_transport for R ranks that are threads of this process: mailboxes and barriers instead of messages"""
 
-    def __init__(self, R):
+    def __init__(self, R, fail_rank=None, fail_at=None):
+        """fail_rank / fail_at: that rank's halo callback returns an error at its fail_at-th call (a one-sided failure)"""
         self.R = R
+        self.fail_rank, self.fail_at, self.calls = fail_rank, fail_at, 0
         self.bar = threading.Barrier(R)
         self.vals = [None] * R
         self.need = [None] * R
@@ -64,6 +66,13 @@ class ThreadTransport:
             return t
 
         def halo(user, send_lo, n_send_lo, send_hi, n_send_hi, recv_lo, n_recv_lo, recv_hi, n_recv_hi, stream):
+            if r == me.fail_rank:
+                me.calls += 1
+                if me.calls == me.fail_at:
+                    # this rank's exchange fails before it posts anything; like an asynchronous send / recv the neighbours'
+                    # exchanges still return (their data is stale -- the solver must not use it: everybody leaves at the reduction)
+                    me.bar.wait(); me.bar.wait()
+                    return 1
             ctx.synchronize()
             if r > 0 and n_send_lo:
                 me.mail[(r, r - 1)] = d2h(send_lo, n_send_lo)
@@ -71,13 +80,15 @@ class ThreadTransport:
                 me.mail[(r, r + 1)] = d2h(send_hi, n_send_hi)
             me.bar.wait()
             if r > 0 and n_recv_lo:
-                t = me.mail[(r - 1, r)]
-                assert t.numel() == n_recv_lo
-                ctx.copy_to_device(recv_lo, t.data_ptr(), 8 * n_recv_lo)
+                t = me.mail.get((r - 1, r))                 # (after a neighbour's failure: its previous message, or none yet)
+                if t is not None:
+                    assert t.numel() == n_recv_lo
+                    ctx.copy_to_device(recv_lo, t.data_ptr(), 8 * n_recv_lo)
             if r + 1 < R and n_recv_hi:
-                t = me.mail[(r + 1, r)]
-                assert t.numel() == n_recv_hi
-                ctx.copy_to_device(recv_hi, t.data_ptr(), 8 * n_recv_hi)
+                t = me.mail.get((r + 1, r))
+                if t is not None:
+                    assert t.numel() == n_recv_hi
+                    ctx.copy_to_device(recv_hi, t.data_ptr(), 8 * n_recv_hi)
             me.bar.wait()
             return 0
 
@@ -136,7 +147,7 @@ def test_ranks_reproduce_the_whole_mesh_solve(N, cd, fd, parts):
             out[r] = e
             tt.bar.abort()
 
-    th = [threading.Thread(target=run, args=(r,)) for r in range(R)]
+    th = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(R)]
     for t in th:
         t.start()
     for t in th:
@@ -151,6 +162,51 @@ def test_ranks_reproduce_the_whole_mesh_solve(N, cd, fd, parts):
     assert x.numel() == n
     scale = float(xw.abs().max())
     assert float((x - xw.cpu()).abs().max()) < 1e-7 * scale
+
+
+@pytest.mark.parametrize("fail_rank,fail_at", [(1, 3), (0, 1), (2, 7)])
+def test_one_sided_failure_ends_the_solve_on_every_rank(fail_rank, fail_at):
+    """One rank's neighbour exchange fails in iteration fail_at: that rank returns status 1 (PA_ERR_COMM), the others status 3
+    ("another rank failed"), all from the same reduction -- nobody is left waiting in a collective."""
+    import torch
+    from proton_amd.capi import ProtonAmdError
+    N, cd, fd, parts = 12, 2, 1, (0, 4, 8, 12)
+    slabs, halo = [], None
+    for r0, r1 in zip(parts[:-1], parts[1:]):
+        s = _slab_system(N, cd, fd, (r0, r1), halo)
+        halo = s[6]
+        slabs.append(s)
+    R = len(slabs)
+    tt = ThreadTransport(R, fail_rank, fail_at)
+    out, keep = [None] * R, []
+    gen = torch.Generator().manual_seed(99)
+
+    def run(r):
+        s, inf, rps, cis, vs, bs, _ = slabs[r]
+        tp, cbs = tt.make(r, s.ctx)
+        keep.append(cbs)
+        bs = (bs.cpu() + torch.rand(bs.numel(), generator=torch.Generator().manual_seed(r), dtype=torch.float64) - 0.5).to(s.device)
+        x = torch.zeros_like(bs)
+        try:
+            s.ctx.conjugated_gradient_rows(tp, inf.row_begin, inf.row_end, rps.data_ptr(), cis.data_ptr(), vs.data_ptr(), bs.data_ptr(),
+                                           x.data_ptr(), tol=1e-13, max_iter=10000)
+            out[r] = "converged"
+        except ProtonAmdError as e:
+            out[r] = (e.status, str(e))
+        except BaseException as e:      # noqa: BLE001
+            out[r] = e
+            tt.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(R)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert all(not t.is_alive() for t in th), "a rank is still inside the solve"
+    for r, o in enumerate(out):
+        assert isinstance(o, tuple), (r, o)
+        assert o[0] == 7, o                                              # PA_ERR_COMM on every rank
+        assert ("transport status 1" in o[1]) == (r == fail_rank) and ("transport status 3" in o[1]) == (r != fail_rank), (r, o)
 
 
 def test_rccl_transport_of_one_rank():
