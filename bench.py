@@ -206,7 +206,7 @@ def cpu_baseline(w, sample_rows, target_seconds=6.0):
 class Pipeline:
     """The step of one rank: its slab of the mesh, its buffers, the sequence of library calls of one pass."""
 
-    def __init__(self, torch, pa, w, mode, rows, N, device_index, comm=None, host_exchange=None):
+    def __init__(self, torch, pa, w, mode, rows, N, device_index, comm=None, host_exchange=None, gather=None):
         from proton_amd.batch import BatchAssembler
         self.torch, self.pa, self.w, self.mode, self.N = torch, pa, w, mode, N
         self.quad = pa.QUAD_TENSOR if w["quad"] == "tensor" else pa.QUAD_FAN
@@ -215,6 +215,10 @@ class Pipeline:
         self.sz = pa.sizes_for(self.di, self.quad)
         self.asm = BatchAssembler(device_index)
         self.comm, self.host_exchange = comm, host_exchange
+        # --exchange allgather: (world, largest nnz_owned, largest row count over the ranks) -- after the fill every rank gathers
+        # every rank's CSR values and right-hand side (the north star's literal collective); None: the halo rows are all that travels
+        self.gather = gather
+        self.host_gather = None
         self._side = self._pin_out = self._pin_in = self._ev_pack = None
         asm, sz, dev = self.asm, self.sz, self.asm.device
         self.cut = bool(w.get("cut"))
@@ -251,6 +255,12 @@ class Pipeline:
             self.b = torch.empty(max(ci.row_end - ci.row_begin, 1), **f64)
             self.halo_out = torch.empty((max(ci.halo_cells, 1), ci.halo_doubles), **f64)
             self.halo_in = torch.zeros((N, ci.halo_doubles), **f64) if ci.has_below else None
+            if gather is not None:
+                world_, max_nnz, max_rows = gather
+                self.values = torch.zeros(max_nnz, **f64)          # (padded to the largest slab: all-gather wants equal counts)
+                self.b = torch.zeros(max_rows, **f64)
+                self.all_values = torch.empty(world_ * max_nnz, **f64)
+                self.all_b = torch.empty(world_ * max_rows, **f64)
         self.ev = {}
 
     def _tick(self, i, name):
@@ -304,6 +314,18 @@ class Pipeline:
         asm.ctx.condensed_csr_fill(di, self.rec.data_ptr(), self.g.data_ptr(), None if self.halo_in is None else self.halo_in.data_ptr(),
                                    self.values.data_ptr(), self.b.data_ptr())
         self._tick(i, "fill")
+        if self.gather is not None:
+            world_, max_nnz, max_rows = self.gather
+            if self.comm is not None:
+                self.comm.allgather_start(self.values.data_ptr(), self.all_values.data_ptr(), 8 * max_nnz)
+                self.comm.wait()
+                self.comm.allgather_start(self.b.data_ptr(), self.all_b.data_ptr(), 8 * max_rows)
+                self.comm.wait()
+            elif self.host_gather is not None:
+                self.torch.cuda.current_stream().synchronize()
+                self.host_gather(self.values, self.all_values, max_nnz)
+                self.host_gather(self.b, self.all_b, max_rows)
+            self._tick(i, "allgather")
 
     def _exchange_start(self):
         ci = self.ci
@@ -415,6 +437,10 @@ def main():
     ap.add_argument("--backend", default=os.environ.get("PA_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl = RCCL, one rank per GPU (what the driver runs); gloo = rehearsal of the N>1 code path with "
                          "several ranks sharing the visible GPU(s) and a host-staged exchange (numbers not comparable)")
+    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
+                    help="N>1, mode C.  halo (default): the packed top-face rows of each slab, one slab up, are all that travels.  allgather: "
+                         "behind it the north star's literal collective -- every rank all-gathers every rank's CSR values and right-hand "
+                         "side (pa_comm_allgather_start) and ends the step holding the whole face-only system")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rccl-timeout", type=float, default=180.0,
                     help="N>1: seconds to wait for the RCCL communicator before the step falls back to the host-staged exchange")
@@ -464,7 +490,19 @@ def main():
         dist.barrier()
 
     r0, r1 = row_partition(N, world, rank)
-    pipe = Pipeline(torch, pa, w, mode, (r0, r1), N, local_rank)
+    gather = None
+    if world > 1 and mode == "C" and args.exchange == "allgather":
+        di_, _ = pa.degree_info(w["cd"], w["fd"])
+        infos = [pa.capi.condensed_partition_info(N, N, row_partition(N, world, r), di_) for r in range(world)]
+        gather = (world, None, max(int(i.row_end - i.row_begin) for i in infos))
+    pipe = Pipeline(torch, pa, w, mode, (r0, r1), N, local_rank, gather=None)
+    if gather is not None:
+        # nnz of the owned rows is known after the symbolic phase: the largest over the ranks sizes the padded buffers
+        mx = torch.tensor([int(pipe.ci.nnz_owned)])
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        gather = (world, int(mx[0]), gather[2])
+        del pipe
+        pipe = Pipeline(torch, pa, w, mode, (r0, r1), N, local_rank, gather=gather)
     if world > 1 and mode == "C":
         from proton_amd.partition import HostStagedHalo
         if not rehearsal:
@@ -511,6 +549,9 @@ def main():
         if rehearsal:
             host_exchange = HostStagedHalo(rank, world)
             pipe.host_exchange = host_exchange
+            if gather is not None:
+                from proton_amd.partition import HostStagedAllgather
+                pipe.host_gather = HostStagedAllgather(rank, world)
         dist.barrier()                                     # communicators exist before anything is timed
 
     n_settle = settle(torch, dist, world, pipe.step, args.settle_ms * 1e-3)
@@ -547,12 +588,21 @@ def main():
             loc = torch.tensor([float(pipe.values.sum()), float(pipe.values.abs().sum()), float(pipe.b.sum()), float(pipe.b.abs().sum())],
                                dtype=torch.float64)
             dist.all_reduce(loc, op=dist.ReduceOp.SUM)
+            if gather is not None:
+                # (the padding is zero: the gathered copy of ANY rank must sum to the same whole-mesh system)
+                got = torch.tensor([float(pipe.all_values.sum()), float(pipe.all_values.abs().sum()), float(pipe.all_b.sum()),
+                                    float(pipe.all_b.abs().sum())], dtype=torch.float64)
+                worst = (got - loc).abs() / torch.tensor([max(abs(float(loc[1])), 1e-300)] * 2 + [max(abs(float(loc[3])), 1e-300)] * 2, dtype=torch.float64)
+                dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+                gathered_ok = bool(float(worst.max()) <= 1e-9)
             if rank == 0:
-                exchange_checked = all(abs(a - r) <= 1e-9 * max(abs(ref_sums[1 if i < 2 else 3]), 1e-300) for i, (a, r) in enumerate(zip(loc.tolist(), ref_sums)))
+                if gather is not None and not gathered_ok:
+                    print("bench.py: a rank's all-gathered system does NOT sum to the ranks' systems (relative %r)" % worst.tolist(), file=sys.stderr, flush=True)
+                exchange_checked = (gather is None or gathered_ok) and all(abs(a - r) <= 1e-9 * max(abs(ref_sums[1 if i < 2 else 3]), 1e-300) for i, (a, r) in enumerate(zip(loc.tolist(), ref_sums)))
                 if not exchange_checked:      # reported in the line (and loudly here), not fatal: the timing is still a measurement
                     print("bench.py: the ranks' systems do NOT add up to the whole-mesh system: %r vs %r" % (loc.tolist(), ref_sums), file=sys.stderr, flush=True)
 
-    names = ("rhs", "ops", "exchange_wait", "fill", "cut", "merge")
+    names = ("rhs", "ops", "exchange_wait", "fill", "allgather", "cut", "merge")
     t = torch.tensor([elapsed, kern_ms] + [stages.get(k, 0.0) for k in names], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -612,6 +662,10 @@ def main():
                     % (N, pipe.ci.halo_doubles, N * pipe.ci.halo_doubles * 8 / 1e6,
                        ("host-staged gloo (NOT RCCL%s)" % ((": RCCL failed to initialise -- " + rccl_error) if rccl_error else ", --backend gloo rehearsal"))
                        if rehearsal else "RCCL send/recv through pa_comm_halo_exchange_start"))
+            if gather is not None:
+                exch += ("; THEN the north star's all-gather: every rank's CSR values (%d doubles, padded) and right-hand side (%d) to every rank "
+                         "(%.2f GB received per rank and step), %s" % (gather[1], gather[2], (world - 1) * (gather[1] + gather[2]) * 8 / 1e9,
+                                                                      "host-staged gloo" if rehearsal else "pa_comm_allgather_start (RCCL)"))
         res = {
             "metric": BASELINE_METRIC,
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -171,7 +171,7 @@ hipError_t asm_pattern(hipStream_t stream, const CondMesh &m, int cbs, int fbs, 
 // position e % R): consecutive lanes write consecutive entries.  The reads run along a row of the column-major lc (stride
 // msize); the lines they touch are shared by the rows of the cell and stay in the vector L1 / L2.
 template <int CBS, int FBS, int U>
-__global__ __launch_bounds__(256) void asm_fill_cells_kernel(AsmDims d, const uint32_t *__restrict__ cell_faces,
+__global__ __launch_bounds__(256) void asm_fill_cells_kernel(AsmDims d, uint32_t c_begin, uint32_t c_end, const uint32_t *__restrict__ cell_faces,
                                                              const int32_t *__restrict__ face_compress,
                                                              const uint32_t *__restrict__ cprefix, const double *__restrict__ lc,
                                                              const double *__restrict__ rhs, const double *__restrict__ g,
@@ -186,8 +186,8 @@ __global__ __launch_bounds__(256) void asm_fill_cells_kernel(AsmDims d, const ui
     uint32_t cell[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const uint32_t c = wave * U + u;
-        on[u] = c < d.ncells;
+        const uint32_t c = c_begin + wave * U + u;
+        on[u] = c < c_end;
         cell[u] = on[u] ? c : 0u;
         cf[u] = cell_faces_sorted(cell_faces, face_compress, cell[u]);
         cpre[u] = cprefix[cell[u]];
@@ -274,7 +274,7 @@ __device__ __forceinline__ double asm_face_rhs_contrib(const uint32_t *cell_face
 
 // Face rows: one wavefront per U faces at a time, lane e of a pass = entry e of the face's block of fbs rows.
 template <int CBS, int FBS, int U>
-__global__ __launch_bounds__(256) void asm_fill_faces_kernel(AsmDims d, const uint32_t *__restrict__ cell_faces,
+__global__ __launch_bounds__(256) void asm_fill_faces_kernel(AsmDims d, uint32_t q_begin, uint32_t q_end, const uint32_t *__restrict__ cell_faces,
                                                              const int32_t *__restrict__ face_compress,
                                                              const CondFaceLean *__restrict__ lean, const uint32_t *__restrict__ colprefix,
                                                              const uint32_t *__restrict__ fprefix, const double *__restrict__ lc,
@@ -289,8 +289,8 @@ __global__ __launch_bounds__(256) void asm_fill_faces_kernel(AsmDims d, const ui
     bool on[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const uint32_t q = wave * U + u;
-        on[u] = q < d.nown;
+        const uint32_t q = q_begin + wave * U + u;
+        on[u] = q < q_end;
         const uint32_t qq = on[u] ? q : 0u;
         r[u] = lean[qq];
         cpre[u] = colprefix[qq];
@@ -361,23 +361,44 @@ __global__ __launch_bounds__(256) void asm_fill_faces_kernel(AsmDims d, const ui
                     const double w = dcols ? asm_face_rhs_contrib<CBS, FBS>(cell_faces, face_compress, lc, g, r[u].cB, rowB) : 0.0;
                     b = have ? b + w : w;
                 }
-                RHS[(size_t)d.cbs * d.ncells + (size_t)(wave * U + u) * FBS + lane] = b;
+                RHS[(size_t)d.cbs * d.ncells + (size_t)(q_begin + wave * U + u) * FBS + lane] = b;
             }
         }
     }
 }
 
+// cells / faces a wavefront has in flight at a time (their descriptors, then their gathers)
+#ifndef PA_ASM_UNROLL
+#define PA_ASM_UNROLL 2
+#endif
+// lc of the cells of one piece of the numeric phase (see asm_fill_t).  One piece: the pieces were meant to keep a piece's lc in
+// the Infinity Cache between its cell rows and its face rows (lc fetched from HBM once instead of 1.7 times) -- measured SLOWER at
+// 1024 x 1024: k = 2 3.35 ms in one piece, 3.68 in pieces of 96 MB, 4.87 in pieces of 32 MB (k = 3: 6.3 / 7.4 / 10.3): the tails of
+// the extra launches cost more than the second fetch
+#ifndef PA_ASM_PIECE_BYTES
+#define PA_ASM_PIECE_BYTES ((size_t)1 << 40)
+#endif
 template <int CBS, int FBS>
 static hipError_t asm_fill_t(hipStream_t stream, const CondMesh &m, const AsmDims &d, const CondFaceLean *lean, const uint32_t *colprefix,
                              const uint32_t *cprefix, const uint32_t *fprefix, const double *lc, const double *rhs, const double *g,
                              double *values, double *RHS)
 {
-    constexpr int U = 2;
-    hipLaunchKernelGGL((asm_fill_cells_kernel<CBS, FBS, U>), dim3(((size_t)d.ncells + 4 * U - 1) / (4 * U)), dim3(256), 0, stream, d,
-                       m.cell_faces, m.face_compress, cprefix, lc, rhs, g, values, RHS);
-    if (d.nown)
-        hipLaunchKernelGGL((asm_fill_faces_kernel<CBS, FBS, U>), dim3(((size_t)d.nown + 4 * U - 1) / (4 * U)), dim3(256), 0, stream, d,
-                           m.cell_faces, m.face_compress, lean, colprefix, fprefix, lc, g, values, RHS);
+    constexpr int U = PA_ASM_UNROLL;
+    // (in pieces of about PA_ASM_PIECE_BYTES of lc -- the cell rows of a piece, then the face rows of the same fraction of the
+    // compressed faces; one piece by default, see above)
+    constexpr size_t lc_bytes = (size_t)(CBS + 4 * FBS) * (CBS + 4 * FBS) * 8;
+    const size_t piece_cells = PA_ASM_PIECE_BYTES / lc_bytes ? PA_ASM_PIECE_BYTES / lc_bytes : 1;
+    const uint32_t npieces = (uint32_t)((d.ncells + piece_cells - 1) / piece_cells);
+    for (uint32_t p = 0; p < npieces; ++p) {
+        const uint32_t c0 = (uint32_t)((uint64_t)d.ncells * p / npieces), c1 = (uint32_t)((uint64_t)d.ncells * (p + 1) / npieces);
+        const uint32_t q0 = (uint32_t)((uint64_t)d.nown * p / npieces), q1 = (uint32_t)((uint64_t)d.nown * (p + 1) / npieces);
+        if (c1 > c0)
+            hipLaunchKernelGGL((asm_fill_cells_kernel<CBS, FBS, U>), dim3(((size_t)(c1 - c0) + 4 * U - 1) / (4 * U)), dim3(256), 0, stream, d, c0, c1,
+                               m.cell_faces, m.face_compress, cprefix, lc, rhs, g, values, RHS);
+        if (q1 > q0)
+            hipLaunchKernelGGL((asm_fill_faces_kernel<CBS, FBS, U>), dim3(((size_t)(q1 - q0) + 4 * U - 1) / (4 * U)), dim3(256), 0, stream, d, q0, q1,
+                               m.cell_faces, m.face_compress, lean, colprefix, fprefix, lc, g, values, RHS);
+    }
     return hipGetLastError();
 }
 

@@ -58,6 +58,23 @@ class HostStagedHalo:
             recv_below.copy_(staged)
 
 
+class HostStagedAllgather:
+    """pa_comm_allgather_start + pa_comm_wait on host copies over gloo -- the north star's literal collective: every rank
+    contributes `count` doubles (its owned CSR values / right-hand side, padded to the largest rank's count) and ends with
+    all ranks' pieces, rank r's at [r * count, (r + 1) * count).  Blocking."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def __call__(self, send, recv, count):
+        assert recv.numel() >= self.world * count
+        mine = torch.zeros(count, dtype=send.dtype)
+        mine[:min(count, send.numel())] = send.detach().reshape(-1)[:count].cpu()
+        parts = [torch.empty(count, dtype=send.dtype) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        recv.reshape(-1)[:self.world * count].copy_(torch.cat(parts))
+
+
 class HostStagedCgTransport:
     """The transport of pa_conjugated_gradient_rows (include/proton_amd.h: pa_cg_transport) on host copies over gloo -- the twin
     of pa_comm_cg_transport for the tests and the one-GPU rehearsal: ranks in slab order, neighbours r - 1 and r + 1."""

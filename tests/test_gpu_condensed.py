@@ -244,6 +244,55 @@ def test_condensed_slabs_equal_whole_mesh(asm, N, cd, fd, parts):
     assert row_end == whole[3].numel() and nnz_end == whole[2].numel()
 
 
+def test_config5_slabs_equal_whole_mesh_at_full_size():
+    """configs[4] of BASELINE.json in the mode the N > 1 bench runs, at its own size: 2048 x 2048, k = 3, the cell rows
+    block-partitioned into the 8 slabs of 8 GPUs -- here one after the other on the one GPU, each with its own context, its own
+    records and the REAL packed top-face rows of the slab below (pa_condensed_halo_pack -> d_halo_below, what pa_comm_halo_exchange
+    carries).  Stacked, the slabs' row pointers, column indices, CSR values and right-hand sides are the whole-mesh
+    pa_condensed_csr_fill bit for bit (7.5 GB of values compared on the device)."""
+    import gc
+    import torch
+    import proton_amd as pa
+    from proton_amd.batch import BatchAssembler
+    from proton_amd.partition import row_partition
+    N, cd, fd, R = 2048, 4, 3, 8
+
+    def slab(rows):
+        a = BatchAssembler(0)
+        a.generate_mesh(N, N, rows=rows)
+        rhs = a.cell_rhs(cd, pa.capi.FN_SIN_SIN_RHS, pa.QUAD_TENSOR)
+        g = a.dirichlet_data(fd, pa.capi.FN_SIN_SIN_SOL)
+        rec = a.condensed_ops(cd, fd, pa.QUAD_TENSOR, pa.STAB_FANCY, rhs=rhs)
+        return a, rec, g
+
+    a, rec, g = slab((0, N))
+    rp, ci = a.condensed_csr_pattern(cd, fd)
+    va, ba = a.condensed_csr_fill(cd, fd, rec, g)
+    a.synchronize()
+    assert va.numel() > 900_000_000 and bool(torch.isfinite(va[::997]).all())
+    del rec
+    halo = None
+    row_end, nnz_end = 0, 0
+    for r in range(R):
+        r0, r1 = row_partition(N, R, r)
+        s, srec, sg = slab((r0, r1))
+        info = s.condensed_info(cd, fd)
+        assert info.row_begin == row_end and bool(info.has_below) == (r0 > 0) and info.halo_cells == (N if r1 < N else 0)
+        rps, cis = s.condensed_csr_pattern(cd, fd)
+        vs, bs = s.condensed_csr_fill(cd, fd, srec, sg, halo_below=halo)
+        halo = s.condensed_halo_pack(cd, fd, srec, sg).clone() if r1 < N else None
+        s.synchronize()
+        nrows = info.row_end - info.row_begin
+        assert torch.equal(rps + nnz_end, rp[row_end:row_end + nrows + 1])
+        assert torch.equal(cis, ci[nnz_end:nnz_end + info.nnz_owned])
+        assert torch.equal(vs, va[nnz_end:nnz_end + info.nnz_owned]), "slab %d: CSR values differ from the whole-mesh fill" % r
+        assert torch.equal(bs, ba[row_end:row_end + nrows])
+        row_end, nnz_end = info.row_end, nnz_end + info.nnz_owned
+        del s, srec, sg, rps, cis, vs, bs
+        gc.collect()
+    assert row_end == ba.numel() and nnz_end == va.numel()
+
+
 def test_condensed_mode_on_an_uploaded_mesh_and_status_codes(asm, oracle):
     """explicit face tables (pa_mesh_set_faces) give the same condensed system as the generator's closed forms;
     bad arguments come back as status codes"""

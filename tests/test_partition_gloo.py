@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from proton_amd.partition import HostStagedHalo, cell_counts, row_partition
+from proton_amd.partition import HostStagedAllgather, HostStagedHalo, cell_counts, row_partition
 
 
 def test_row_partition_covers_all_rows():
@@ -148,7 +148,18 @@ def _worker(rank, world, port, N, cd, fd, q):
         dist.barrier()
         HostStagedHalo(rank, world)(send, recv)
         A, b = _assemble_owned(ref, di, N, r0, r1, info, S, g, None if recv is None else recv.numpy())
-        q.put((rank, (int(info.row_begin), A, b)))
+        # the north star's literal collective behind the halo exchange: all-gather of every rank's owned rows (padded to the
+        # largest slab's count), after which EVERY rank holds the whole face-only system (HostStagedAllgather = the host twin of
+        # pa_comm_allgather_start)
+        rows_all = [capi.condensed_partition_info(N, N, row_partition(N, world, r), pdi) for r in range(world)]
+        nrows = [int(i.row_end - i.row_begin) for i in rows_all]
+        count = max(nrows) * (info.system_size + 1)
+        mine = torch.from_numpy(np.concatenate([A, b[:, None]], axis=1).reshape(-1))
+        gathered = torch.empty(world * count, dtype=torch.float64)
+        HostStagedAllgather(rank, world)(mine, gathered, count)
+        whole = np.concatenate([gathered[r * count:r * count + nrows[r] * (info.system_size + 1)].numpy().reshape(nrows[r], info.system_size + 1)
+                                for r in range(world)])
+        q.put((rank, (int(info.row_begin), A, b, whole)))
     finally:
         dist.destroy_process_group()
 
@@ -176,7 +187,11 @@ def test_slabs_with_halo_exchange_equal_the_whole_system(N, cd, fd, world):
     assert A.shape[0] == info.system_size and abs(A - A.T).max() < 1e-12 * abs(A).max()
     row = 0
     for r in range(world):
-        begin, Ar, br = results[r]
+        begin, Ar, br, whole = results[r]
+        # after the all-gather every rank holds the same whole system [A | b]
+        assert whole.shape == (info.system_size, info.system_size + 1)
+        assert np.abs(whole[:, :-1] - A).max() <= 1e-15 * np.abs(A).max() and np.abs(whole[:, -1] - b).max() <= 1e-15 * max(1.0, np.abs(b).max())
+        assert np.array_equal(whole, results[0][3])
         assert begin == row
         # the same sums of the same two addends: equal up to the order of the additions of a shared face's two cells
         assert np.abs(Ar - A[row:row + Ar.shape[0]]).max() <= 1e-15 * np.abs(A).max()
