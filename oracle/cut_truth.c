@@ -90,6 +90,7 @@ static void q_normals(const q_t pts[8], q_t n[8])               /* basic_geom.hp
         q_t vx = pts[2 * k] - pts[2 * i], vy = pts[2 * k + 1] - pts[2 * i + 1];
         q_t nrm = sqrtq(vx * vx + vy * vy);
         n[2 * i] = vy / nrm; n[2 * i + 1] = -vx / nrm;
+        if (g_round_inputs == 2) { n[2 * i] = (double)n[2 * i]; n[2 * i + 1] = (double)n[2 * i + 1]; }
     }
 }
 
@@ -105,6 +106,10 @@ static q_t q_ipow(q_t x, int n) { q_t r = 1; for (int i = 0; i < n; i++) r *= x;
 static void q_cell_basis(const q_t bar[2], q_t h, int degree, q_t x, q_t y, q_t *phi, q_t *gx, q_t *gy)
 {                                                               /* bases.hpp:85-190 */
     q_t bx = (x - bar[0]) / (h / 2), by = (y - bar[1]) / (h / 2), ih = 2 / h;
+    if (g_round_inputs == 2) {      /* attribution: the scaled coordinates of a point (and 2/h) rounded to double, everything else exact */
+        const double db = (double)bar[0], dc = (double)bar[1], dh = (double)h;
+        bx = (q_t)(((double)x - db) * (1.0 / (0.5 * dh))); by = (q_t)(((double)y - dc) * (1.0 / (0.5 * dh))); ih = (q_t)(2.0 / dh);
+    }
     int pos = 0;
     for (int k = 0; k <= degree; k++)
         for (int i = 0; i <= k; i++) {
@@ -124,6 +129,7 @@ static void q_face_basis(const q_t p0[2], const q_t p1[2], int degree, q_t x, q_
     q_t dx = p1[0] - p0[0], dy = p1[1] - p0[1];
     q_t h2 = dx * dx + dy * dy;
     q_t ep = 4 * ((barx - p0[0]) * (x - barx) + (bary - p0[1]) * (y - bary)) / h2;
+    if (g_round_inputs == 2) ep = (double)ep;
     for (int i = 0; i <= degree; i++) phi[i] = q_ipow(ep, i);
 }
 
@@ -133,6 +139,7 @@ static void q_ls_normal(const cut_level_set *ls, q_t x, q_t y, q_t n[2])
         q_t gx = 2 * x - 2 * (q_t)ls->alpha, gy = 2 * y - 2 * (q_t)ls->beta;
         q_t nr = sqrtq(gx * gx + gy * gy);
         n[0] = gx / nr; n[1] = gy / nr;
+        if (g_round_inputs == 2) { n[0] = (double)n[0]; n[1] = (double)n[1]; }
     } else { n[0] = 0; n[1] = 1; }
 }
 
@@ -215,7 +222,8 @@ int cut_truth_laplacian(const cut_mesh *m, const cut_level_set *ls, size_t c, hh
             q_t dnj = gx[j] * n[0] + gy[j] * n[1];
             for (int i = 0; i < rbs; i++) {
                 q_t dni = gx[i] * n[0] + gy[i] * n[1];
-                stiff[IDX(i, j, rbs)] += (q_t)qw[q] * (phi[i] * phi[j] * Q_ETA / hT - phi[i] * dnj - dni * phi[j]);
+                const q_t eta_h = g_round_inputs == 2 ? (q_t)(5.0 / (double)hT) : Q_ETA / hT;
+                stiff[IDX(i, j, rbs)] += (q_t)qw[q] * (phi[i] * phi[j] * eta_h - phi[i] * dnj - dni * phi[j]);
             }
         }
     }
@@ -239,7 +247,7 @@ int cut_truth_laplacian(const cut_mesh *m, const cut_level_set *ls, size_t c, hh
             }
         }
     }
-    if (g_round_inputs) {
+    if (g_round_inputs == 1) {
         for (int i = 0; i < rbs * rbs; i++) L[i] = (double)L[i];
         for (int i = 0; i < rbs * msize; i++) gr_rhs[i] = (double)gr_rhs[i];
     }

@@ -1670,6 +1670,14 @@ static int cut_local_ops(pa_context *ctx, int face_deg, const pa_level_set *ls, 
         a.rhs_fn = rhs_fn; a.bcs_fn = bcs_fn; a.rhs_vals = d_rhs_vals; a.bcs_vals = d_bcs_vals;
         a.eta = 5.0;                                                             // cell_eta, cuthho_square.cpp:301-306
         a.oper = d_oper; a.data = d_data; a.stab = d_stab; a.lc = d_lc; a.rhs = d_rhs; a.info = d_info;
+        a.dbg = nullptr;
+#ifdef PA_TUNING
+        static long long *d_cut_dbg = nullptr;
+        if (std::getenv("PA_CUT_CLOCK")) {
+            if (!d_cut_dbg) (void)hipMalloc((void **)&d_cut_dbg, 16 * sizeof(long long));
+            a.dbg = d_cut_dbg;
+        }
+#endif
         // one wavefront per cut cell and a long serial chain per cell: as many blocks as the chip holds (2 per SIMD),
         // so that a few thousand cut cells take ONE cell's latency, not two or three
         size_t cap_blocks = (size_t)ctx->num_cus * 8;
@@ -1685,14 +1693,35 @@ static int cut_local_ops(pa_context *ctx, int face_deg, const pa_level_set *ls, 
             if (e == hipSuccess) e = hipStreamWaitEvent(ctx->side, ctx->ev_main, 0);
             st_ = ctx->side;
         }
+        bool cut_dd = true;           // stages A-E in double-double (cut_device.hpp); the all-double form is an A/B of tuning builds
+#ifdef PA_TUNING
+        if (const char *env = std::getenv("PA_CUT_DOUBLE")) cut_dd = std::atoi(env) == 0;
+#endif
         if (e == hipSuccess) {
-            switch (face_deg) {
-            case 0: hipLaunchKernelGGL((pa::cut_local_ops_kernel<0>), dim3(grid), dim3(64), 0, st_, a); break;
-            case 1: hipLaunchKernelGGL((pa::cut_local_ops_kernel<1>), dim3(grid), dim3(64), 0, st_, a); break;
-            default: hipLaunchKernelGGL((pa::cut_local_ops_kernel<2>), dim3(grid), dim3(64), 0, st_, a); break;
+            if (cut_dd) {
+                switch (face_deg) {
+                case 0: hipLaunchKernelGGL((pa::cut_local_ops_kernel<0, true>), dim3(grid), dim3(64), 0, st_, a); break;
+                case 1: hipLaunchKernelGGL((pa::cut_local_ops_kernel<1, true>), dim3(grid), dim3(64), 0, st_, a); break;
+                default: hipLaunchKernelGGL((pa::cut_local_ops_kernel<2, true>), dim3(grid), dim3(64), 0, st_, a); break;
+                }
+            } else {
+                switch (face_deg) {
+                case 0: hipLaunchKernelGGL((pa::cut_local_ops_kernel<0, false>), dim3(grid), dim3(64), 0, st_, a); break;
+                case 1: hipLaunchKernelGGL((pa::cut_local_ops_kernel<1, false>), dim3(grid), dim3(64), 0, st_, a); break;
+                default: hipLaunchKernelGGL((pa::cut_local_ops_kernel<2, false>), dim3(grid), dim3(64), 0, st_, a); break;
+                }
             }
             e = hipGetLastError();
         }
+#ifdef PA_TUNING
+        if (a.dbg != nullptr && e == hipSuccess) {
+            long long h[16] = {0};
+            (void)hipStreamSynchronize(st_);
+            (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "PA_CUT_CLOCK block 0 (last cell it worked on), clocks per stage: A %lld stiff %lld B %lld C %lld D %lld solve %lld E %lld F %lld H %lld\n",
+                         h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[9] - h[8]);
+        }
+#endif
         if (e == hipSuccess && st_ != ctx->stream) {
             e = hipEventRecord(ctx->ev_side, ctx->side);
             ctx->side_pending = true;

@@ -22,18 +22,14 @@ def nerr(a, b):
 
 
 def judge_cut_cells(ref, oracle, di, cells, got_lc, got_oper=None, got_data=None, label=""):
-    """Every cut cell against the binary128 evaluation of the reference's formulas from the same double quadrature lists
-    (oracle/cut_truth.c, pinned by the 50-digit fixtures of tests/golden/cut_ops.npz), next to the double-precision oracle
-    (the reference's operation order) judged the same way.  The Nitsche-penalised rbs x rbs system of a sliver is badly
-    conditioned (1-norm condition numbers to 1.9e9 on the 512 x 512 mesh): merely ROUNDING gr_lhs / gr_rhs to double and
-    solving exactly costs up to 1e-11 in `data` there (tests/test_oracle_cut_truth.py), so no double evaluation -- Eigen's,
-    the oracle's, the kernel's -- is within 1e-12 of another on those cells.  Asserted:
-      * 1e-12 on every cell whose condition number allows it (cond < 1e5), for lc, data and oper alike;
-      * on every cell the envelope the reference's own operation order stays inside, 1e-12 + 1e-15 cond (lc, data);
-      * the kernel is not the worse side: over the cells where either error exceeds 1e-13 the geometric mean of
-        err_gpu / err_oracle is <= 2 (two independent roundings of cond * eps differ cell by cell, in either direction);
-      * and it loses no more cells beyond 1e-12 than the oracle does (+ 2 %).
-    -> dict of the per-cell arrays (printed by the caller)."""
+    """EVERY cut cell within 1e-12 of the binary128 evaluation of the reference's formulas from the same double quadrature lists
+    (oracle/cut_truth.c, pinned by the 50-digit fixtures of tests/golden/cut_ops.npz): lc, data and oper alike, slivers
+    included (1-norm condition numbers of the Nitsche-penalised rbs x rbs system to 1.9e9 on the 512 x 512 mesh).  The cut kernel
+    forms the sums, the factorization, the substitutions and the final product in double-double (cut_device.hpp) -- in double no
+    evaluation can do this: merely ROUNDING gr_lhs / gr_rhs to double and solving exactly costs up to 1e-11 in `data`
+    (tests/test_oracle_cut_truth.py), and the reference's own operation order in double (the oracle, judged here the same way and
+    printed next to the kernel) sits at 1e-10 on the worst cells, beyond 1e-12 on one cell in six.
+    -> dict of the per-cell arrays."""
     rows = []
     for i, c in enumerate(cells):
         c = int(c)
@@ -52,23 +48,12 @@ def judge_cut_cells(ref, oracle, di, cells, got_lc, got_oper=None, got_data=None
         rows.append((ref.truth_cond(c, di), e_gpu, e_orc, e_gd, e_go, e_oo))
     r = np.array(rows)
     cond, e_gpu, e_orc, e_gd, e_go, e_oo = r.T
-    n_g, n_o = int((e_gpu > TOL).sum()), int((e_orc > TOL).sum())
-    worse = int((e_gpu > np.maximum(TOL, 2 * e_orc)).sum())
-    print("%s cut cells %d | cond median %.1e max %.1e | lc vs binary128: GPU median %.1e max %.1e, oracle median %.1e max %.1e | "
-          "beyond 1e-12: GPU %d, oracle %d | GPU worse than 2x oracle (and > 1e-12): %d | oper: GPU max %.1e, oracle max %.1e"
+    print("%s cut cells %d | cond median %.1e max %.1e | lc vs binary128: GPU median %.1e max %.1e, oracle (double, reference order) median %.1e "
+          "max %.1e | beyond 1e-12: GPU %d, oracle %d | oper: GPU max %.1e, oracle max %.1e"
           % (label, len(cells), np.median(cond), cond.max(), np.median(e_gpu), e_gpu.max(), np.median(e_orc), e_orc.max(),
-             n_g, n_o, worse, e_go.max(), e_oo.max()))
-    ok = cond < 1e5
-    assert np.all(e_gpu[ok] < TOL) and np.all(e_gd[ok] < TOL), (e_gpu[ok].max(), e_gd[ok].max())
-    assert np.all(e_go[cond < 1e3] < TOL)                      # oper itself carries the full cond * eps
-    env = TOL + 1e-15 * cond
-    assert np.all(e_gpu < env) and np.all(e_gd < env), (np.max(e_gpu / env), np.max(e_gd / env))
-    assert np.all(e_go < TOL + 1e-14 * cond), np.max(e_go / (TOL + 1e-14 * cond))
-    big = np.maximum(e_gpu, e_orc) > 1e-13
-    gm = float(np.exp(np.mean(np.log(e_gpu[big] / e_orc[big])))) if big.any() else 1.0
-    print("   geometric mean of err_gpu / err_oracle over the %d cells beyond 1e-13: %.2f" % (int(big.sum()), gm))
-    assert gm <= 2.0, gm
-    assert n_g <= n_o + max(1, len(cells) // 50), (n_g, n_o)
+             int((e_gpu > TOL).sum()), int((e_orc > TOL).sum()), e_go.max(), e_oo.max()))
+    assert np.all(e_gpu < TOL), (int((e_gpu >= TOL).sum()), e_gpu.max())
+    assert np.all(e_gd < TOL) and np.all(e_go < TOL), (e_gd.max(), e_go.max())
     return dict(cond=cond, e_gpu=e_gpu, e_orc=e_orc)
 
 
@@ -398,7 +383,7 @@ def test_config3_at_full_size_cut_cells_merged(asm, oracle):
     asym = (lc - lc.transpose(1, 2)).abs().amax(dim=(1, 2)) / scale
     is_cut = torch.from_numpy(ref.cell_loc == oracle.CUT_ON_INTERFACE).to(lc.device)
     assert float(asym[~is_cut].max()) < 1e-12
-    assert float(asym[is_cut].max()) < 1e-9          # slivers: cond * eps of the Nitsche-penalised system (judge_cut_cells)
+    assert float(asym[is_cut].max()) < 1e-12         # (data of a cut cell is formed in double-double and rounded once)
     outside = torch.from_numpy(ref.cell_loc == oracle.CUT_POS).to(lc.device)
     assert int(outside.sum()) > 0 and float(rhs[outside].abs().max()) == 0.0
     assert float(rhs[~outside].abs().amax(dim=1).min()) > 0.0
