@@ -19,16 +19,23 @@ for f in glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True):
         acc[k][c].append(v)
 out = {"workload": workload, "mode": mode, "kernels": {}}
 dominant = 0.0
+# the kernels bench.py's roofline.kernel_ms spans: L / A -- the local operators (pre-pass + cooperative kernel, or the thread-per-cell
+# kernel of the small pairs; with cut cells also their kernel and the merge); C -- every kernel of the step (cell rhs, operators with
+# the condensation fused, CSR fill)
+DOM = ["hho_local_ops_kernel", "hho_cell_pre_kernel", "hho_small_ops_kernel", "cut_local_ops_kernel", "cut_merge_cells_kernel", "cut_zero_rhs_kernel"]
+if mode == "C":
+    DOM += ["cell_rhs_kernel", "cond_fill_kernel", "cond_rhs_rows_kernel"]
+STEP_KERNELS = DOM + ["cell_rhs_kernel", "cond_fill_kernel", "cond_rhs_rows_kernel", "asm_fill_cells_kernel", "asm_fill_faces_kernel", "dirichlet_data_kernel"]
 for k, cs in sorted(acc.items()):
     ndisp = max(len(v) for v in cs.values())
-    per_step = ndisp / STEPS if ("hho_local_ops_kernel" in k or "hho_cell_pre_kernel" in k or "cond_fill" in k or "cell_rhs" in k) and ndisp >= STEPS else 1.0
+    per_step = ndisp / STEPS if any(n in k for n in STEP_KERNELS) and ndisp >= STEPS else 1.0
     m = {c: sum(v) / len(v) * per_step for c, v in cs.items()}
     rec = {"dispatches_per_step": per_step, "per_step_sums" if per_step != 1.0 else "per_dispatch_means": m}
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         rec["FETCH_SIZE_bytes"] = m["FETCH_SIZE"] * 1024
         rec["WRITE_SIZE_bytes"] = m["WRITE_SIZE"] * 1024
         rec["hbm_bytes_per_launch_gfx950_corrected"] = 2 * rec["FETCH_SIZE_bytes"] + rec["WRITE_SIZE_bytes"]
-        if "hho_local_ops_kernel" in k or "hho_cell_pre_kernel" in k:
+        if any(n in k for n in DOM):
             dominant += rec["hbm_bytes_per_launch_gfx950_corrected"]
     if "SQ_LDS_BANK_CONFLICT" in m and m.get("SQ_LDS_IDX_ACTIVE"):
         rec["lds_bank_conflict_frac"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]
@@ -40,6 +47,7 @@ if len(sys.argv) > 4:
     try:
         b = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
         out["bench_kernel_ms_under_profiler"] = b["roofline"]["kernel_ms"]
+        out["build_stamp"] = b.get("build_stamp")
         out["algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes_per_cell"] * b["roofline"]["cells_per_launch"]
     except Exception as e:      # noqa: BLE001
         out["bench_line_error"] = str(e)
@@ -51,7 +59,7 @@ if len(sys.argv) > 5 and os.path.exists(sys.argv[5]) and "bench_line_error" not 
         nsteps = b["steps"] + b["warmup"] + (b.get("settle") or {}).get("passes", 0)
         per = {}
         for r in csv.DictReader(open(sys.argv[5])):
-            if "hho_local_ops_kernel" in r["Name"] or "hho_cell_pre_kernel" in r["Name"]:
+            if any(n in r["Name"] for n in DOM):
                 per[r["Name"][:110]] = {"calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]),
                                         "ms_per_step": int(r["Calls"]) * float(r["AverageNs"]) / nsteps * 1e-6}
         out["rocprof_kernel_stats"] = {"steps_under_profiler": nsteps, "kernels": per,
