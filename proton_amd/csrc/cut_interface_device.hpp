@@ -34,16 +34,26 @@ struct CutInterfaceArgs {
     int32_t *info;
 };
 
-template <int FD>
+// DD (the default): the two-sided reconstruction system in double-double, like the one-sided one (cut_device.hpp, section 3.2 of
+// DESIGN.md): its pinned (2 rbs - 1) system is badly conditioned on EVERY cut cell (1-norm condition numbers: median 1e7 at k = 2).
+template <int FD, bool DD = true>
 __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a)
 {
     constexpr int RD = FD + 1, RBS = P2(RD), CBS = RBS, FBS = FD + 1, NF = 4 * FBS, MS = CBS + NF;
     constexpr int N2 = 2 * RBS, M2 = 2 * MS, NR = N2 - 1, LD2 = (N2 + 1) & ~1, LDR = (NR + 1) & ~1;
     constexpr int NMOM = P2(2 * RD), NFPT = 4 * FACE_SLOTS, CH = 64, NPW = 2 * RD + 1;
     constexpr int PW = 2 * NPW + 1, ROWW = imax(2 * RBS, PW);
-    constexpr int oMOM = 0, oST = (oMOM + NMOM + 1) & ~1, oLL = oST + LD2 * N2, oGR = oLL + LDR * NR + (LDR * NR & 1);
-    constexpr int oOP = oGR + N2 * M2, oTPHI = oOP + N2 * M2, oTDN = oTPHI + CH * RBS, oTW = oTPHI + CH * ROWW;
+    constexpr int W = DD ? 2 : 1;                               // DD: (hi, lo) pairs; the pinned system is factored in place in ST
+    constexpr int oMOM = 0, oST = (oMOM + W * NMOM + 1) & ~1, oLL = oST + W * LD2 * N2, oGR = DD ? oLL : oLL + LDR * NR + (LDR * NR & 1);
+    constexpr int oOP = oGR + W * N2 * M2, oTPHI = oOP + W * N2 * M2, oTDN = oTPHI + CH * RBS, oTW = oTPHI + CH * ROWW;
     constexpr int oFB = oTW + CH, oEND = oFB + NFPT * FBS;
+    // DD tables on the point table: stage B, chunks of CHB points: phi, then w dn; afterwards the sums A (rbs^2 pairs) and C; stage C:
+    // phi and w dn of the NFPT face points, then their face-basis values
+    constexpr int CHB = imin(32, (CH * ROWW) / (4 * RBS));      // (<= 32: a pair per point in the CH doubles of the weight table)
+    constexpr int oBPH = oTPHI, oBDN = oTPHI + 2 * CHB * RBS, oBA = oTPHI, oBC = oTPHI + 2 * RBS * RBS;
+    constexpr int oCPH = oTPHI, oCDN = oTPHI + 2 * NFPT * RBS, oCFB = oCDN + 2 * NFPT * RBS;
+    static_assert(!DD || (4 * CHB * RBS <= CH * ROWW && 4 * RBS * RBS <= CH * ROWW && oCFB + 2 * NFPT * FBS <= oTPHI + CH * ROWW && CHB >= 1),
+                  "the double-double tables fit the point table");
     static_assert(M2 <= 64 && NMOM <= 64 && NR <= 64, "one lane per column / moment / row");
     __shared__ __attribute__((aligned(16))) double S[oEND];
     const int l = threadIdx.x;
@@ -91,114 +101,154 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
             gy = r == 0 ? 0.0 : r * ih * ipow(bx, p) * ipow(by, r - 1);
         };
 
-        for (int e = l; e < LD2 * N2; e += 64) S[oST + e] = 0.0;
+        int bad = 0;
+        if constexpr (DD) {
+        for (int e = l; e < 2 * LD2 * N2; e += 64) S[oST + e] = 0.0;
         wave_sync();
-
-        // ---- A: per side, cell moments -> kappa_s * stiffness block (:419-432) and the volume
-        // right-hand side of that side (cuthho_utils.hpp:75-81; degree == recdeg: the same points)
-        int mp = 0, mr = 0, rp = 0, rr = 0;
-        if (l < NMOM) mono_exps(l, mp, mr);
-        if (l < CBS) mono_exps(l, rp, rr);
+        const dd ih2 = two_prod(ih, ih);
+        // ---- A: per side, moments over the side's cut quadrature (one lane per POINT, double-double accumulators, butterfly over the
+        // lanes) -> kappa_s * stiffness block (:419-432); the side's volume right-hand side rides along in double (cuthho_utils.hpp:75-81)
 #pragma unroll 1
         for (int side = 0; side < 2; ++side) {
             const uint32_t c0 = a.cell_off[side][cc], c1 = a.cell_off[side][cc + 1];
             const double *xyw = a.cell_xyw[side];
-            double mom_acc = 0.0, rhs_acc = 0.0;
-            for (uint32_t base = c0; base < c1; base += CH) {
-                const uint32_t q = base + l;
-                if (q < c1) {
+            {
+                dd macc[NMOM];
+                double racc[CBS];
+#pragma unroll
+                for (int m = 0; m < NMOM; ++m) macc[m] = dd_from(0.0);
+#pragma unroll
+                for (int m = 0; m < CBS; ++m) racc[m] = 0.0;
+                for (uint32_t q = c0 + l; q < c1; q += 64) {
                     const double x = xyw[3 * q], y = xyw[3 * q + 1], w = xyw[3 * q + 2];
                     const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
-                    double vx = w, vy = 1.0;
-                    for (int e = 0; e < NPW; ++e) {
-                        S[oTPHI + l * ROWW + e] = vx;
-                        S[oTPHI + l * ROWW + NPW + e] = vy;
-                        vx *= bx; vy *= by;
+                    dd pbx[NPW], pby[NPW];                  // w bx^e, by^e
+                    pbx[0] = dd_from(w); pby[0] = dd_from(1.0);
+#pragma unroll
+                    for (int e = 1; e < NPW; ++e) { pbx[e] = dd_mul_d(pbx[e - 1], bx); pby[e] = dd_mul_d(pby[e - 1], by); }
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k)
+#pragma unroll
+                        for (int r = 0; r <= k; ++r) macc[k * (k + 1) / 2 + r] = dd_add_fast(macc[k * (k + 1) / 2 + r], dd_mul(pbx[k - r], pby[r]));
+                    if (a.rhs != nullptr) {
+                        const double fv = builtin_fn(a.rhs_fn, x, y);
+#pragma unroll
+                        for (int k = 0; k <= RD; ++k)
+#pragma unroll
+                            for (int r = 0; r <= k; ++r) racc[k * (k + 1) / 2 + r] += fv * (pbx[k - r].hi * pby[r].hi);
                     }
-                    S[oTPHI + l * ROWW + 2 * NPW] = a.rhs != nullptr ? builtin_fn(a.rhs_fn, x, y) : 0.0;
                 }
-                wave_sync();
-                const int nq = (int)((c1 - base) < (uint32_t)CH ? (c1 - base) : (uint32_t)CH);
-                if (l < NMOM)
-                    for (int t = 0; t < nq; ++t) mom_acc += S[oTPHI + t * ROWW + mp] * S[oTPHI + t * ROWW + NPW + mr];
-                if (l < CBS)
-                    for (int t = 0; t < nq; ++t)
-                        rhs_acc += (S[oTPHI + t * ROWW + rp] * S[oTPHI + t * ROWW + NPW + rr]) * S[oTPHI + t * ROWW + 2 * NPW];
-                wave_sync();
+#pragma unroll
+                for (int m = 0; m < NMOM; ++m) {
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        const dd o = dd{__shfl_xor(macc[m].hi, off), __shfl_xor(macc[m].lo, off)};
+                        macc[m] = dd_add_fast(macc[m], o);
+                    }
+                    if (l == m) dd_store(S + oMOM + 2 * m, macc[m]);
+                }
+                if (a.rhs != nullptr) {
+#pragma unroll
+                    for (int m = 0; m < CBS; ++m) {
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) racc[m] += __shfl_xor(racc[m], off);
+                        if (l == m) a.rhs[(size_t)cc * (2 * CBS) + side * CBS + m] = racc[m];      // :1710-1711
+                    }
+                }
             }
-            if (l < NMOM) S[oMOM + l] = mom_acc;
-            if (a.rhs != nullptr && l < CBS) a.rhs[(size_t)cc * (2 * CBS) + side * CBS + l] = rhs_acc;      // :1710-1711
             wave_sync();
-            const double ks = a.kappa[side] * ih * ih;
+            const dd ks = dd_mul_d(ih2, a.kappa[side]);
             for (int e = l; e < RBS * RBS; e += 64) {
                 int ai, bi, aj, bj;
                 mono_exps(e % RBS, ai, bi);
                 mono_exps(e / RBS, aj, bj);
-                double v = 0.0;
-                if (ai * aj) v += (double)(ai * aj) * S[oMOM + mono_index(ai + aj - 2, bi + bj)];
-                if (bi * bj) v += (double)(bi * bj) * S[oMOM + mono_index(ai + aj, bi + bj - 2)];
-                S[oST + (side * RBS + e % RBS) + (side * RBS + e / RBS) * LD2] = ks * v;
+                dd v = dd_from(0.0);
+                if (ai * aj) v = dd_add(v, dd_mul_d(dd_load(S + oMOM + 2 * mono_index(ai + aj - 2, bi + bj)), (double)(ai * aj)));
+                if (bi * bj) v = dd_add(v, dd_mul_d(dd_load(S + oMOM + 2 * mono_index(ai + aj, bi + bj - 2)), (double)(bi * bj)));
+                dd_store(S + oST + 2 * ((side * RBS + e % RBS) + (side * RBS + e / RBS) * LD2), dd_mul(v, ks));
             }
             wave_sync();
         }
-
-        // ---- B: interface terms (:437-459) with a = k1 w phi (dphi.n)^T, b = a^T, c = k1 w eta/hT phi phi^T:
-        //   (-,-) -= a + b - c ;  (+,-) += a - c ;  (-,+) += b - c ;  (+,+) += c
+        auto basis_dd = [&](double bx, double by, dd (&phi)[RBS], dd (&gx)[RBS], dd (&gy)[RBS]) {
+            dd pbx[RD + 1], pby[RD + 1];
+            pbx[0] = dd_from(1.0); pby[0] = dd_from(1.0);
+#pragma unroll
+            for (int e = 1; e <= RD; ++e) { pbx[e] = dd_mul_d(pbx[e - 1], bx); pby[e] = dd_mul_d(pby[e - 1], by); }
+            int m = 0;
+#pragma unroll
+            for (int kk = 0; kk <= RD; ++kk)
+#pragma unroll
+                for (int ii = 0; ii <= kk; ++ii, ++m) {
+                    const int p_ = kk - ii, r_ = ii;
+                    phi[m] = dd_mul(pbx[p_], pby[r_]);
+                    gx[m] = p_ == 0 ? dd_from(0.0) : dd_mul(dd_mul(pbx[p_ > 0 ? p_ - 1 : 0], pby[r_]), two_prod((double)p_, ih));
+                    gy[m] = r_ == 0 ? dd_from(0.0) : dd_mul(dd_mul(pbx[p_], pby[r_ > 0 ? r_ - 1 : 0]), two_prod((double)r_, ih));
+                }
+        };
+        // ---- B: interface terms (:437-459): A_ij = sum k1 w phi_i (dphi_j.n), C_ij = sum k1 w eta/hT phi_i phi_j, entry per lane;
+        //   (-,-) += C - A - A^T ;  (+,-) += A - C ;  (-,+) += A^T - C ;  (+,+) += C
         {
             const uint32_t i0 = a.il_off[cc], i1 = a.il_off[cc + 1];
-            double acc_a[(RBS * RBS + 63) / 64], acc_at[(RBS * RBS + 63) / 64], acc_c[(RBS * RBS + 63) / 64];
+            constexpr int NU = (RBS * RBS + 63) / 64;
+            dd accA[NU], accC[NU];
 #pragma unroll
-            for (int u = 0; u < (RBS * RBS + 63) / 64; ++u) acc_a[u] = acc_at[u] = acc_c[u] = 0.0;
-            for (uint32_t base = i0; base < i1; base += CH) {
+            for (int u = 0; u < NU; ++u) accA[u] = accC[u] = dd_from(0.0);
+            for (uint32_t base = i0; base < i1; base += CHB) {
                 const uint32_t q = base + l;
-                if (q < i1) {
+                if (l < CHB && q < i1) {
                     const double x = a.il_xyw[3 * q], y = a.il_xyw[3 * q + 1];
                     const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
                     double nx, ny;
                     a.ls.normal(x, y, nx, ny);
-                    for (int m = 0; m < RBS; ++m) {
-                        double gx, gy;
-                        grad_m(bx, by, m, gx, gy);
-                        S[oTPHI + l * RBS + m] = phi_m(bx, by, m);
-                        S[oTDN + l * RBS + m] = gx * nx + gy * ny;
-                    }
-                    S[oTW + l] = a.kappa[0] * a.il_xyw[3 * q + 2];
-                } else S[oTW + l] = 0.0;
-                wave_sync();
-                const int nq = (int)((i1 - base) < (uint32_t)CH ? (i1 - base) : (uint32_t)CH);
+                    dd phi[RBS], gx[RBS], gy[RBS];
+                    basis_dd(bx, by, phi, gx, gy);
+                    const dd kw = two_prod(a.kappa[0], a.il_xyw[3 * q + 2]);
 #pragma unroll
-                for (int u = 0; u < (RBS * RBS + 63) / 64; ++u) {
+                    for (int m = 0; m < RBS; ++m) {
+                        dd_store(S + oBPH + 2 * (l * RBS + m), phi[m]);
+                        dd_store(S + oBDN + 2 * (l * RBS + m), dd_mul(dd_add(dd_mul_d(gx[m], nx), dd_mul_d(gy[m], ny)), kw));   // k1 w dn
+                    }
+                    dd_store(S + oTW + 2 * l, dd_mul_d(kw, eta_h));                                                             // k1 w eta/hT
+                }
+                wave_sync();
+                const int nq = (int)((i1 - base) < (uint32_t)CHB ? (i1 - base) : (uint32_t)CHB);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
                     const int e = l + 64 * u;
                     if (e < RBS * RBS) {
                         const int i = e % RBS, j = e / RBS;
                         for (int t = 0; t < nq; ++t) {
-                            const double w = S[oTW + t], pi_ = S[oTPHI + t * RBS + i], pj = S[oTPHI + t * RBS + j];
-                            acc_a[u] += w * pi_ * S[oTDN + t * RBS + j];
-                            acc_at[u] += w * S[oTDN + t * RBS + i] * pj;
-                            acc_c[u] += w * eta_h * pi_ * pj;
+                            const dd fi = dd_load(S + oBPH + 2 * (t * RBS + i)), fj = dd_load(S + oBPH + 2 * (t * RBS + j));
+                            accA[u] = dd_add_fast(accA[u], dd_mul(fi, dd_load(S + oBDN + 2 * (t * RBS + j))));
+                            accC[u] = dd_add_fast(accC[u], dd_mul(dd_mul(fi, fj), dd_load(S + oTW + 2 * t)));
                         }
                     }
                 }
                 wave_sync();
             }
 #pragma unroll
-            for (int u = 0; u < (RBS * RBS + 63) / 64; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 const int e = l + 64 * u;
-                if (e < RBS * RBS) {
-                    const int i = e % RBS, j = e / RBS;
-                    S[oST + i + j * LD2] += -acc_a[u] - acc_at[u] + acc_c[u];
-                    S[oST + (RBS + i) + j * LD2] += acc_a[u] - acc_c[u];
-                    S[oST + i + (RBS + j) * LD2] += acc_at[u] - acc_c[u];
-                    S[oST + (RBS + i) + (RBS + j) * LD2] += acc_c[u];
-                }
+                if (e < RBS * RBS) { dd_store(S + oBA + 2 * e, accA[u]); dd_store(S + oBC + 2 * e, accC[u]); }
+            }
+            wave_sync();
+            for (int e = l; e < RBS * RBS; e += 64) {
+                const int i = e % RBS, j = e / RBS;
+                const dd A_ = dd_load(S + oBA + 2 * (i + j * RBS)), At = dd_load(S + oBA + 2 * (j + i * RBS)), C_ = dd_load(S + oBC + 2 * (i + j * RBS));
+                double *p00 = S + oST + 2 * (i + j * LD2), *p10 = S + oST + 2 * ((RBS + i) + j * LD2);
+                double *p01 = S + oST + 2 * (i + (RBS + j) * LD2), *p11 = S + oST + 2 * ((RBS + i) + (RBS + j) * LD2);
+                dd_store(p00, dd_add(dd_load(p00), dd_sub(dd_sub(C_, A_), At)));
+                dd_store(p10, dd_add(dd_load(p10), dd_sub(A_, C_)));
+                dd_store(p01, dd_add(dd_load(p01), dd_sub(At, C_)));
+                dd_store(p11, dd_add(dd_load(p11), C_));
             }
             wave_sync();
         }
-
         // ---- C: gr_rhs (:461-495).  Columns: [cell- | cell+ | faces- | faces+]
         for (int e = l; e < N2 * M2; e += 64) {
             const int i = e % N2, j = e / N2;
-            S[oGR + e] = j < CBS ? S[oST + i + j * LD2] : (j < 2 * CBS ? S[oST + i + (RBS + j - CBS) * LD2] : 0.0);
+            const dd v = j < CBS ? dd_load(S + oST + 2 * (i + j * LD2)) : (j < 2 * CBS ? dd_load(S + oST + 2 * (i + (RBS + j - CBS) * LD2)) : dd_from(0.0));
+            dd_store(S + oGR + 2 * e, v);
         }
         wave_sync();
 #pragma unroll 1
@@ -207,7 +257,8 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
                 const int f = l / FACE_SLOTS, qq = l % FACE_SLOTS;
                 const bool ok = qq < a.fl_cnt[side][cc * 4 + f];
                 const double *src = a.fl_xyw[side] + (((size_t)cc * 4 + f) * FACE_SLOTS + qq) * 3;
-                const double x = ok ? src[0] : barx, y = ok ? src[1] : bary, w = ok ? a.kappa[side] * src[2] : 0.0;
+                const double x = ok ? src[0] : barx, y = ok ? src[1] : bary;
+                const dd kw = ok ? two_prod(a.kappa[side], src[2]) : dd_from(0.0);
                 const int f1 = (f + 1) & 3;
                 const double ex = px[f1] - px[f], ey = py[f1] - py[f];
                 const double len = sqrt(ex * ex + ey * ey);
@@ -218,65 +269,284 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
                 const double fbx = 0.5 * (ax + bxx), fby = 0.5 * (ay + byy);
                 const double ep = 4.0 * ((fbx - ax) * (x - fbx) + (fby - ay) * (y - fby)) / (len * len);
                 const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
+                dd phi[RBS], gx[RBS], gy[RBS];
+                basis_dd(bx, by, phi, gx, gy);
+#pragma unroll
                 for (int m = 0; m < RBS; ++m) {
-                    double gx, gy;
-                    grad_m(bx, by, m, gx, gy);
-                    S[oTPHI + l * RBS + m] = phi_m(bx, by, m);
-                    S[oTDN + l * RBS + m] = w * (gx * nx + gy * ny);
+                    dd_store(S + oCPH + 2 * (l * RBS + m), phi[m]);
+                    dd_store(S + oCDN + 2 * (l * RBS + m), dd_mul(dd_add(dd_mul_d(gx[m], nx), dd_mul_d(gy[m], ny)), kw));
                 }
-                for (int k = 0; k < FBS; ++k) S[oFB + l * FBS + k] = ipow(ep, k);
+                dd pe = dd_from(1.0);
+#pragma unroll
+                for (int k = 0; k < FBS; ++k) { dd_store(S + oCFB + 2 * (l * FBS + k), pe); pe = dd_mul_d(pe, ep); }
             }
             wave_sync();
             for (int e = l; e < RBS * MS; e += 64) {
                 const int i = e % RBS, j = e / RBS;
                 if (j < CBS) {                                              // :479, :491
-                    double s = 0.0;
-                    for (int p = 0; p < NFPT; ++p) s += S[oTDN + p * RBS + i] * S[oTPHI + p * RBS + j];
-                    S[oGR + (side * RBS + i) + (side * CBS + j) * N2] -= s;
+                    double *dst = S + oGR + 2 * ((side * RBS + i) + (side * CBS + j) * N2);
+                    dd sacc = dd_load(dst);
+                    for (int p_ = 0; p_ < NFPT; ++p_) sacc = dd_sub_fast(sacc, dd_mul(dd_load(S + oCDN + 2 * (p_ * RBS + i)), dd_load(S + oCPH + 2 * (p_ * RBS + j))));
+                    dd_store(dst, sacc);
                 } else {                                                    // :480-481, :492-493
                     const int f = (j - CBS) / FBS, k = (j - CBS) % FBS;
-                    double s = 0.0;
-                    for (int qq = 0; qq < FACE_SLOTS; ++qq) s += S[oTDN + (f * FACE_SLOTS + qq) * RBS + i] * S[oFB + (f * FACE_SLOTS + qq) * FBS + k];
-                    S[oGR + (side * RBS + i) + (2 * CBS + side * NF + f * FBS + k) * N2] = s;
+                    dd sacc = dd_from(0.0);
+                    for (int qq = 0; qq < FACE_SLOTS; ++qq)
+                        sacc = dd_add_fast(sacc, dd_mul(dd_load(S + oCDN + 2 * ((f * FACE_SLOTS + qq) * RBS + i)), dd_load(S + oCFB + 2 * ((f * FACE_SLOTS + qq) * FBS + k))));
+                    dd_store(S + oGR + 2 * ((side * RBS + i) + (2 * CBS + side * NF + f * FBS + k) * N2), sacc);
                 }
             }
             wave_sync();
         }
-
-        // ---- D: oper = gr_lhs^+ gr_rhs with the first unknown pinned (see the header comment)
-        for (int e = l; e < NR * LDR; e += 64) {
-            const int i = e / LDR, k = e % LDR;
-            S[oLL + e] = k < NR ? S[oST + (i + 1) + (k + 1) * LD2] : 0.0;
-        }
-        wave_sync();
-        const int bad = lds_cholesky<NR, LDR, 64, 2>(S + oLL, l);
+        // ---- D: the first unknown pinned (see the header comment): Cholesky of ST[1:, 1:] in place, lane i = row i (of the pinned
+        // system); 1 / L_jj in the (dead) moment table -- 2 NR <= 2 NMOM doubles
         {
-            double x[NR];
-            const int c = l < M2 ? l : 0;
-#pragma unroll
-            for (int k = 0; k < NR; ++k) x[k] = S[oGR + (k + 1) + c * N2];
-            lds_forward<NR, LDR>(S + oLL, x);
-            lds_backward<NR, LDR>(S + oLL, x);
-            if (l < M2) {
-                S[oOP + c * N2] = 0.0;
-#pragma unroll
-                for (int k = 0; k < NR; ++k) S[oOP + (k + 1) + c * N2] = x[k];
+            static_assert(NR <= NMOM, "the reciprocal pivots fit the moment table");
+            double *RS = S + oMOM;
+            auto LP = [&](int i, int j) -> double * { return S + oST + 2 * ((i + 1) + (j + 1) * LD2); };
+#pragma unroll 1
+            for (int j = 0; j < NR; ++j) {
+                dd sj = dd_from(0.0);
+                if (l >= j && l < NR) {
+                    sj = dd_load(LP(l, j));
+                    for (int k = 0; k < j; ++k) sj = dd_sub(sj, dd_mul(dd_load(LP(l, k)), dd_load(LP(j, k))));
+                    if (l == j) dd_store(LP(j, j), sj);
+                }
+                wave_sync();
+                const dd piv = dd_load(LP(j, j));
+                if (!(piv.hi > 0.0) && !bad) bad = j + 1;
+                const dd rs = dd_rsqrt(piv);
+                wave_sync();
+                if (l >= j && l < NR) dd_store(LP(l, j), dd_mul(sj, rs));
+                if (l == 0) dd_store(RS + 2 * j, rs);
+                wave_sync();
             }
+            if (l < M2) {
+                dd xv[NR];
+#pragma unroll
+                for (int k = 0; k < NR; ++k) xv[k] = dd_load(S + oGR + 2 * ((k + 1) + l * N2));
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    dd sv = xv[i];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) sv = dd_sub_fast(sv, dd_mul(dd_load(LP(i, k)), xv[k]));
+                    xv[i] = dd_mul(sv, dd_load(RS + 2 * i));
+                }
+#pragma unroll
+                for (int i = NR - 1; i >= 0; --i) {
+                    dd sv = xv[i];
+#pragma unroll
+                    for (int k = i + 1; k < NR; ++k) sv = dd_sub_fast(sv, dd_mul(dd_load(LP(k, i)), xv[k]));
+                    xv[i] = dd_mul(sv, dd_load(RS + 2 * i));
+                }
+                dd_store(S + oOP + 2 * (l * N2), dd_from(0.0));
+#pragma unroll
+                for (int k = 0; k < NR; ++k) dd_store(S + oOP + 2 * ((k + 1) + l * N2), xv[k]);
+            }
+            wave_sync();
+            if (a.oper != nullptr)
+                for (int e = l; e < N2 * M2; e += 64) a.oper[(size_t)cc * (N2 * M2) + e] = dd_round(dd_load(S + oOP + 2 * e));
         }
-        wave_sync();
-        if (a.oper != nullptr)
-            for (int e = l; e < N2 * M2; e += 64) a.oper[(size_t)cc * (N2 * M2) + e] = S[oOP + e];
-
-        // ---- E: data = gr_rhs^T oper (:499)
+        // ---- E: data = gr_rhs^T oper (:499), rounded once
         if (a.data != nullptr) {
             const size_t off = (size_t)cc * (M2 * M2);
 #pragma unroll 1
             for (int e = l; e < M2 * M2; e += 64) {
                 const int i = e % M2, j = e / M2;
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < N2; ++k) s += S[oGR + k + i * N2] * S[oOP + k + j * N2];
-                a.data[off + e] = s;
+                dd sacc = dd_from(0.0);
+#pragma unroll 4
+                for (int k = 0; k < N2; ++k) sacc = dd_add_fast(sacc, dd_mul(dd_load(S + oGR + 2 * (k + i * N2)), dd_load(S + oOP + 2 * (k + j * N2))));
+                a.data[off + e] = dd_round(sacc);
+            }
+        }
+        } else {
+            for (int e = l; e < LD2 * N2; e += 64) S[oST + e] = 0.0;
+            wave_sync();
+
+            // ---- A: per side, cell moments -> kappa_s * stiffness block (:419-432) and the volume
+            // right-hand side of that side (cuthho_utils.hpp:75-81; degree == recdeg: the same points)
+            int mp = 0, mr = 0, rp = 0, rr = 0;
+            if (l < NMOM) mono_exps(l, mp, mr);
+            if (l < CBS) mono_exps(l, rp, rr);
+    #pragma unroll 1
+            for (int side = 0; side < 2; ++side) {
+                const uint32_t c0 = a.cell_off[side][cc], c1 = a.cell_off[side][cc + 1];
+                const double *xyw = a.cell_xyw[side];
+                double mom_acc = 0.0, rhs_acc = 0.0;
+                for (uint32_t base = c0; base < c1; base += CH) {
+                    const uint32_t q = base + l;
+                    if (q < c1) {
+                        const double x = xyw[3 * q], y = xyw[3 * q + 1], w = xyw[3 * q + 2];
+                        const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
+                        double vx = w, vy = 1.0;
+                        for (int e = 0; e < NPW; ++e) {
+                            S[oTPHI + l * ROWW + e] = vx;
+                            S[oTPHI + l * ROWW + NPW + e] = vy;
+                            vx *= bx; vy *= by;
+                        }
+                        S[oTPHI + l * ROWW + 2 * NPW] = a.rhs != nullptr ? builtin_fn(a.rhs_fn, x, y) : 0.0;
+                    }
+                    wave_sync();
+                    const int nq = (int)((c1 - base) < (uint32_t)CH ? (c1 - base) : (uint32_t)CH);
+                    if (l < NMOM)
+                        for (int t = 0; t < nq; ++t) mom_acc += S[oTPHI + t * ROWW + mp] * S[oTPHI + t * ROWW + NPW + mr];
+                    if (l < CBS)
+                        for (int t = 0; t < nq; ++t)
+                            rhs_acc += (S[oTPHI + t * ROWW + rp] * S[oTPHI + t * ROWW + NPW + rr]) * S[oTPHI + t * ROWW + 2 * NPW];
+                    wave_sync();
+                }
+                if (l < NMOM) S[oMOM + l] = mom_acc;
+                if (a.rhs != nullptr && l < CBS) a.rhs[(size_t)cc * (2 * CBS) + side * CBS + l] = rhs_acc;      // :1710-1711
+                wave_sync();
+                const double ks = a.kappa[side] * ih * ih;
+                for (int e = l; e < RBS * RBS; e += 64) {
+                    int ai, bi, aj, bj;
+                    mono_exps(e % RBS, ai, bi);
+                    mono_exps(e / RBS, aj, bj);
+                    double v = 0.0;
+                    if (ai * aj) v += (double)(ai * aj) * S[oMOM + mono_index(ai + aj - 2, bi + bj)];
+                    if (bi * bj) v += (double)(bi * bj) * S[oMOM + mono_index(ai + aj, bi + bj - 2)];
+                    S[oST + (side * RBS + e % RBS) + (side * RBS + e / RBS) * LD2] = ks * v;
+                }
+                wave_sync();
+            }
+
+            // ---- B: interface terms (:437-459) with a = k1 w phi (dphi.n)^T, b = a^T, c = k1 w eta/hT phi phi^T:
+            //   (-,-) -= a + b - c ;  (+,-) += a - c ;  (-,+) += b - c ;  (+,+) += c
+            {
+                const uint32_t i0 = a.il_off[cc], i1 = a.il_off[cc + 1];
+                double acc_a[(RBS * RBS + 63) / 64], acc_at[(RBS * RBS + 63) / 64], acc_c[(RBS * RBS + 63) / 64];
+    #pragma unroll
+                for (int u = 0; u < (RBS * RBS + 63) / 64; ++u) acc_a[u] = acc_at[u] = acc_c[u] = 0.0;
+                for (uint32_t base = i0; base < i1; base += CH) {
+                    const uint32_t q = base + l;
+                    if (q < i1) {
+                        const double x = a.il_xyw[3 * q], y = a.il_xyw[3 * q + 1];
+                        const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
+                        double nx, ny;
+                        a.ls.normal(x, y, nx, ny);
+                        for (int m = 0; m < RBS; ++m) {
+                            double gx, gy;
+                            grad_m(bx, by, m, gx, gy);
+                            S[oTPHI + l * RBS + m] = phi_m(bx, by, m);
+                            S[oTDN + l * RBS + m] = gx * nx + gy * ny;
+                        }
+                        S[oTW + l] = a.kappa[0] * a.il_xyw[3 * q + 2];
+                    } else S[oTW + l] = 0.0;
+                    wave_sync();
+                    const int nq = (int)((i1 - base) < (uint32_t)CH ? (i1 - base) : (uint32_t)CH);
+    #pragma unroll
+                    for (int u = 0; u < (RBS * RBS + 63) / 64; ++u) {
+                        const int e = l + 64 * u;
+                        if (e < RBS * RBS) {
+                            const int i = e % RBS, j = e / RBS;
+                            for (int t = 0; t < nq; ++t) {
+                                const double w = S[oTW + t], pi_ = S[oTPHI + t * RBS + i], pj = S[oTPHI + t * RBS + j];
+                                acc_a[u] += w * pi_ * S[oTDN + t * RBS + j];
+                                acc_at[u] += w * S[oTDN + t * RBS + i] * pj;
+                                acc_c[u] += w * eta_h * pi_ * pj;
+                            }
+                        }
+                    }
+                    wave_sync();
+                }
+    #pragma unroll
+                for (int u = 0; u < (RBS * RBS + 63) / 64; ++u) {
+                    const int e = l + 64 * u;
+                    if (e < RBS * RBS) {
+                        const int i = e % RBS, j = e / RBS;
+                        S[oST + i + j * LD2] += -acc_a[u] - acc_at[u] + acc_c[u];
+                        S[oST + (RBS + i) + j * LD2] += acc_a[u] - acc_c[u];
+                        S[oST + i + (RBS + j) * LD2] += acc_at[u] - acc_c[u];
+                        S[oST + (RBS + i) + (RBS + j) * LD2] += acc_c[u];
+                    }
+                }
+                wave_sync();
+            }
+
+            // ---- C: gr_rhs (:461-495).  Columns: [cell- | cell+ | faces- | faces+]
+            for (int e = l; e < N2 * M2; e += 64) {
+                const int i = e % N2, j = e / N2;
+                S[oGR + e] = j < CBS ? S[oST + i + j * LD2] : (j < 2 * CBS ? S[oST + i + (RBS + j - CBS) * LD2] : 0.0);
+            }
+            wave_sync();
+    #pragma unroll 1
+            for (int side = 0; side < 2; ++side) {
+                if (l < NFPT) {
+                    const int f = l / FACE_SLOTS, qq = l % FACE_SLOTS;
+                    const bool ok = qq < a.fl_cnt[side][cc * 4 + f];
+                    const double *src = a.fl_xyw[side] + (((size_t)cc * 4 + f) * FACE_SLOTS + qq) * 3;
+                    const double x = ok ? src[0] : barx, y = ok ? src[1] : bary, w = ok ? a.kappa[side] * src[2] : 0.0;
+                    const int f1 = (f + 1) & 3;
+                    const double ex = px[f1] - px[f], ey = py[f1] - py[f];
+                    const double len = sqrt(ex * ex + ey * ey);
+                    const double nx = ey / len, ny = -ex / len;                      // outward normal of the CELL on both sides (:464)
+                    const bool flip = ids[f] > ids[f1];
+                    const double ax = flip ? px[f1] : px[f], ay = flip ? py[f1] : py[f];
+                    const double bxx = flip ? px[f] : px[f1], byy = flip ? py[f] : py[f1];
+                    const double fbx = 0.5 * (ax + bxx), fby = 0.5 * (ay + byy);
+                    const double ep = 4.0 * ((fbx - ax) * (x - fbx) + (fby - ay) * (y - fby)) / (len * len);
+                    const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
+                    for (int m = 0; m < RBS; ++m) {
+                        double gx, gy;
+                        grad_m(bx, by, m, gx, gy);
+                        S[oTPHI + l * RBS + m] = phi_m(bx, by, m);
+                        S[oTDN + l * RBS + m] = w * (gx * nx + gy * ny);
+                    }
+                    for (int k = 0; k < FBS; ++k) S[oFB + l * FBS + k] = ipow(ep, k);
+                }
+                wave_sync();
+                for (int e = l; e < RBS * MS; e += 64) {
+                    const int i = e % RBS, j = e / RBS;
+                    if (j < CBS) {                                              // :479, :491
+                        double s = 0.0;
+                        for (int p = 0; p < NFPT; ++p) s += S[oTDN + p * RBS + i] * S[oTPHI + p * RBS + j];
+                        S[oGR + (side * RBS + i) + (side * CBS + j) * N2] -= s;
+                    } else {                                                    // :480-481, :492-493
+                        const int f = (j - CBS) / FBS, k = (j - CBS) % FBS;
+                        double s = 0.0;
+                        for (int qq = 0; qq < FACE_SLOTS; ++qq) s += S[oTDN + (f * FACE_SLOTS + qq) * RBS + i] * S[oFB + (f * FACE_SLOTS + qq) * FBS + k];
+                        S[oGR + (side * RBS + i) + (2 * CBS + side * NF + f * FBS + k) * N2] = s;
+                    }
+                }
+                wave_sync();
+            }
+
+            // ---- D: oper = gr_lhs^+ gr_rhs with the first unknown pinned (see the header comment)
+            for (int e = l; e < NR * LDR; e += 64) {
+                const int i = e / LDR, k = e % LDR;
+                S[oLL + e] = k < NR ? S[oST + (i + 1) + (k + 1) * LD2] : 0.0;
+            }
+            wave_sync();
+            bad = lds_cholesky<NR, LDR, 64, 2>(S + oLL, l);
+            {
+                double x[NR];
+                const int c = l < M2 ? l : 0;
+    #pragma unroll
+                for (int k = 0; k < NR; ++k) x[k] = S[oGR + (k + 1) + c * N2];
+                lds_forward<NR, LDR>(S + oLL, x);
+                lds_backward<NR, LDR>(S + oLL, x);
+                if (l < M2) {
+                    S[oOP + c * N2] = 0.0;
+    #pragma unroll
+                    for (int k = 0; k < NR; ++k) S[oOP + (k + 1) + c * N2] = x[k];
+                }
+            }
+            wave_sync();
+            if (a.oper != nullptr)
+                for (int e = l; e < N2 * M2; e += 64) a.oper[(size_t)cc * (N2 * M2) + e] = S[oOP + e];
+
+            // ---- E: data = gr_rhs^T oper (:499)
+            if (a.data != nullptr) {
+                const size_t off = (size_t)cc * (M2 * M2);
+    #pragma unroll 1
+                for (int e = l; e < M2 * M2; e += 64) {
+                    const int i = e % M2, j = e / M2;
+                    double s = 0.0;
+    #pragma unroll
+                    for (int k = 0; k < N2; ++k) s += S[oGR + k + i * N2] * S[oOP + k + j * N2];
+                    a.data[off + e] = s;
+                }
             }
         }
         if (a.info != nullptr && l == 0) a.info[cc] = bad;

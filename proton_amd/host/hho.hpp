@@ -802,7 +802,9 @@ template <typename Mesh>
 class face_numbering {
     using T = typename Mesh::coordinate_type;
     std::vector<double> face_xyw_, g_, samples_;
-    std::vector<size_t> probe_idx_;      // sample positions on Dirichlet faces at which a cached result is re-checked
+    std::vector<size_t> probe_idx_;      // sample positions on Dirichlet faces at which a cached result is re-checked inside a sweep
+    std::vector<size_t> boundary_idx_;   // every sample position on a Dirichlet face: re-checked when a sweep starts
+    size_t last_pos_ = 0;
 
   public:
     std::vector<int64_t> compress;
@@ -818,17 +820,28 @@ class face_numbering {
     static bool dirichlet(const typename Mesh::face_type &fc) { return fc.is_boundary && fc.bndtype == boundary::DIRICHLET; }
 
     // nfaces x fbs coefficients, zeros on faces that are not Dirichlet
+    // `pos`: the offset of the cell an assemble() call is working on (0: a call that is not tied to a cell).
     template <typename Function>
-    const std::vector<double> &dirichlet_data(const Mesh &msh, const Function &bf)
+    const std::vector<double> &dirichlet_data(const Mesh &msh, const Function &bf, size_t pos = 0)
     {
-        // The data of one boundary function serve every cell of an assembly loop.  They are NOT tied to the functor's
-        // address (a re-created temporary may live where the previous functor did): a cached result is reused only
-        // while the functor still takes the cached values at a handful of boundary quadrature points spread over the
-        // Dirichlet faces; two functors that agree at all of them and differ elsewhere need a fresh assembler.
+        // The data of one boundary function serve every cell of an assembly loop.  They are NOT tied to the functor's address (a
+        // re-created temporary may live where the previous functor did).  The reference evaluates the boundary function for every
+        // cell at every assemble (hho.hpp:381-386); here a cached result is reused only while the functor reproduces the cached
+        // samples: at EVERY quadrature point of every Dirichlet face whenever a call starts a new sweep over the cells (pos not
+        // beyond the previous call's: O(boundary faces) functor calls on the host, no device work when they agree) -- two functors
+        // that differ anywhere on the boundary get their own data --, and at a handful of probe points spread over the Dirichlet
+        // faces for the calls that continue a sweep (the per-cell cost of the check must not grow with the boundary).
+        const bool sweep_continues = pos > 0 && pos >= last_pos_;
+        last_pos_ = pos;
         if (!g_.empty()) {
             bool same = true;
-            for (size_t k : probe_idx_)
-                if (bf(typename Mesh::point_type(face_xyw_[3 * k], face_xyw_[3 * k + 1])) != samples_[k]) { same = false; break; }
+            if (sweep_continues) {
+                for (size_t k : probe_idx_)
+                    if (bf(typename Mesh::point_type(face_xyw_[3 * k], face_xyw_[3 * k + 1])) != samples_[k]) { same = false; break; }
+            } else {
+                for (size_t k : boundary_idx_)
+                    if (bf(typename Mesh::point_type(face_xyw_[3 * k], face_xyw_[3 * k + 1])) != samples_[k]) { same = false; break; }
+            }
             if (same) return g_;
         }
         auto &dev = device::instance();
@@ -844,7 +857,8 @@ class face_numbering {
         samples.resize(nf * nq);
         for (size_t k = 0; k < nf * nq; ++k) samples[k] = bf(typename Mesh::point_type(face_xyw_[3 * k], face_xyw_[3 * k + 1]));
         if (probe_idx_.empty()) {
-            std::vector<size_t> on_boundary;
+            std::vector<size_t> &on_boundary = boundary_idx_;
+            on_boundary.clear();
             for (size_t f = 0; f < nf; ++f)
                 if (compress[f] < 0) for (size_t q = 0; q < nq; ++q) on_boundary.push_back(f * nq + q);
             const size_t want = std::min<size_t>(8, on_boundary.size());
@@ -896,7 +910,7 @@ class assembler {
             for (size_t k = 0; k < fbs; ++k) {
                 const size_t l = cbs + lf * fbs + k;
                 if (comp >= 0) gidx[l] = (int64_t)(cbs * ncells + (size_t)comp * fbs + k);
-                else dir[l] = numbering.dirichlet_data(msh, bf)[fids[lf] * fbs + k];
+                else dir[l] = numbering.dirichlet_data(msh, bf, c)[fids[lf] * fbs + k];
             }
         }
     }
@@ -1097,7 +1111,7 @@ class obstacle_assembler {
                     row[l] = (int64_t)(cbs * num_all_cells + (size_t)comp * fbs + k);     // :644
                     col[l] = (int64_t)(cbs * num_I_cells + (size_t)comp * fbs + k);       // :645
                 } else {
-                    known[l] = numbering.dirichlet_data(msh, dirichlet_bf)[fids[lf] * fbs + k];
+                    known[l] = numbering.dirichlet_data(msh, dirichlet_bf, c)[fids[lf] * fbs + k];
                 }
             }
         }

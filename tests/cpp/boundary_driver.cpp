@@ -5,7 +5,10 @@
 //   3. make_hho_fancy_stabilization honours its `reconstruction` argument: the cell's own operator is accepted, any
 //      other matrix is refused (hho.hpp:155-159, 184-190);
 //   4. two proton_amd::device objects in one process, selected with device_scope, hold two different meshes side by side;
-//   5. the per-cell loop body over 65 536 cells stays linear in the number of cells (time bound).
+//   5. the per-cell loop body over 65 536 cells stays linear in the number of cells (time bound);
+//   6. two Dirichlet functors that differ on ONE boundary edge only, given to the same assembler in two consecutive sweeps: the
+//      second sweep's boundary coefficients are those of the second functor, whichever edge it is (the cache of
+//      boundary data was re-checked at 8 probe points only).
 // Prints "check <n> ok" per item; exit code 0 iff all pass.
 #include <chrono>
 #include <cmath>
@@ -124,6 +127,43 @@ int main()
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::printf("per-cell sweep of %zu cells: %.2f s (checksum %.6e)\n", big.cells.size(), sec, acc);
         report(5, std::isfinite(acc) && sec < 20.0);
+    }
+    // 6. boundary data follow the functor on every edge
+    {
+        mesh_type m = make_mesh(6);
+        auto g1 = [](const mesh_type::point_type &pt) -> T { return 1.0 + pt.x() + 2.0 * pt.y(); };
+        bool ok = true;
+        size_t edges = 0;
+        for (size_t f = 0; f < m.faces.size(); ++f) {
+            if (!m.faces[f].is_boundary) continue;
+            ++edges;
+            const auto a = m.points[m.faces[f].ptids[0]], b = m.points[m.faces[f].ptids[1]];
+            const T x0 = std::min(a.x(), b.x()) - 1e-9, x1 = std::max(a.x(), b.x()) + 1e-9;
+            const T y0 = std::min(a.y(), b.y()) - 1e-9, y1 = std::max(a.y(), b.y()) + 1e-9;
+            // g2 = g1 except on the open edge f (its end points belong to the neighbouring edges too, so leave them alone)
+            auto g2 = [=](const mesh_type::point_type &pt) -> T {
+                const bool inside = pt.x() > x0 && pt.x() < x1 && pt.y() > y0 && pt.y() < y1;
+                const bool at_end = (std::abs(pt.x() - a.x()) + std::abs(pt.y() - a.y()) < 1e-9) ||
+                                    (std::abs(pt.x() - b.x()) + std::abs(pt.y() - b.y()) < 1e-9);
+                return 1.0 + pt.x() + 2.0 * pt.y() + ((inside && !at_end) ? 5.0 : 0.0);
+            };
+            auto assm = make_assembler(m, hdi);
+            auto fresh = make_assembler(m, hdi);
+            std::vector<T> sol(assm.RHS.size(), T(0));
+            T seen = 0;
+            for (auto &cl : m.cells) (void)assm.take_local_data(m, cl, sol, g1);              // sweep 1 fills the cache with g1
+            for (auto &cl : m.cells) {                                                         // sweep 2: g2
+                auto got = assm.take_local_data(m, cl, sol, g2);
+                auto want = fresh.take_local_data(m, cl, sol, g2);
+                auto with_g1 = fresh.take_local_data(m, cl, sol, g1);
+                ok = ok && max_abs_diff(got, want) == 0;
+                seen = std::max(seen, max_abs_diff(want, with_g1));
+                (void)fresh.take_local_data(m, cl, sol, g2);                                   // leave `fresh` holding g2 ...
+            }
+            ok = ok && seen > 1.0;                                                             // the bump reached some cell
+        }
+        std::printf("boundary data re-checked on %zu edges\n", edges);
+        report(6, ok && edges == 24);
     }
     return failures ? 1 : 0;
 }

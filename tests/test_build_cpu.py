@@ -53,14 +53,35 @@ def test_local_operator_kernels_of_the_baseline_configurations_do_not_spill():
 def test_dpp_operands_have_no_valu_write_hazard():
     """The substitutions take the packed factor through DPP operands written in inline assembly (hho_device.hpp, Cfg::DPPFWD),
     which the compiler's hazard recognizer does not see: a VALU write of the DPP source register within the two instructions
-    before the DPP read would need wait states.  tools/dpp_lint.py checks the generated ISA of every instance."""
+    before the DPP read would need wait states.  tools/dpp_lint.py checks the generated ISA of every instance: wait states counted
+    (s_nop N = N + 1), branches into a label followed backwards, VALU writes of EXEC within 5 wait states of a DPP instruction."""
     spec = importlib.util.spec_from_file_location("pa_dpp_lint", os.path.join(ROOT, "tools", "dpp_lint.py"))
     lint = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lint)
     with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
-        results = list(ex.map(lint.one, [c for c, _ in BASELINE_INSTANCES]))
+        results = list(ex.map(lint.one, lint.B.configs()))      # EVERY instance of pa_configs.def, not the headline ones only
     assert sum(n for n, _ in results) > 0                     # the instances do use the DPP form
     assert not [b for _, bad in results for b in bad], [b for _, bad in results for b in bad][:5]
+
+
+def test_dpp_lint_sees_the_hazards_it_is_there_for():
+    """synthetic listings: a write one instruction before the read, `s_nop 0` (ONE wait state) between them, a write at the end of a
+    loop body feeding the read at the loop head, a v_cmpx three instructions before a DPP instruction -- and the clean forms of each"""
+    spec = importlib.util.spec_from_file_location("pa_dpp_lint", os.path.join(ROOT, "tools", "dpp_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    dpp = "v_fmac_f64_dpp v[0:1], v[4:5], v[2:3] row_newbcast:3 row_mask:0xf bank_mask:0xf"
+    n, bad = lint.lint_listing(["v_mov_b32_e32 v4, v9", dpp])
+    assert n == 1 and len(bad) == 1
+    assert len(lint.lint_listing(["v_mov_b32_e32 v4, v9", "s_nop 0", dpp])[1]) == 1            # one wait state is not two
+    assert len(lint.lint_listing(["v_mov_b32_e32 v4, v9", "s_nop 1", dpp])[1]) == 0
+    assert len(lint.lint_listing(["v_mov_b32_e32 v4, v9", "v_add_u32 v7, v7, v8", "s_mov_b32 s0, 0", dpp])[1]) == 0
+    loop = [".LBB0_1:", dpp, "v_add_f64 v[6:7], v[6:7], v[0:1]", "v_mov_b32_e32 v5, v9", "s_cbranch_scc1 .LBB0_1"]
+    assert len(lint.lint_listing(loop)[1]) == 1                                                # back edge: write, branch, read
+    loop_ok = [".LBB0_1:", dpp, "v_mov_b32_e32 v5, v9", "v_add_f64 v[6:7], v[6:7], v[0:1]", "s_nop 0", "s_cbranch_scc1 .LBB0_1"]
+    assert len(lint.lint_listing(loop_ok)[1]) == 0
+    assert len(lint.lint_listing(["v_cmpx_gt_u32_e32 16, v0", "v_mov_b32_e32 v20, v9", "v_mov_b32_e32 v21, v9", dpp])[1]) == 1
+    assert len(lint.lint_listing(["v_cmpx_gt_u32_e32 16, v0", "s_nop 4", dpp])[1]) == 0
 
 
 # (instance, mangled-name key of its lc-only kernel, budget of the cell loop: vector instructions, matrix instructions, LDS instructions)

@@ -185,10 +185,10 @@ def test_cut_error_codes(asm):
                                          (12, 1, 3, (1.0, 7.5)), (10, 2, 5, (2.0, 0.5))])
 def test_interface_operators_match_oracle(asm, oracle, N, k, r, kappa):
     """make_hho_laplacian_interface + the stabilization blocks + both right-hand sides of every cut
-    cell, and the kappa-weighted uncut cells.  Uncut cells: 1e-12 against the oracle.  Cut cells: `data` against the
-    binary128 evaluation (oracle/cut_truth.c), next to the oracle's pivoted LDL^T judged the same way -- the two-sided
-    system holds both parts of the cell, so one of them is a sliver wherever the other is regular, and no two double
-    evaluations agree to 1e-12 there (see judge_cut_cells).  `oper`: the product returns the solution with the constant of
+    cell, and the kappa-weighted uncut cells.  Uncut cells: 1e-12 against the oracle.  Cut cells: `data` within 1e-12 of the
+    binary128 evaluation (oracle/cut_truth.c) on EVERY cell, next to the oracle's pivoted LDL^T (double) judged the same way -- the
+    pinned two-sided system is badly conditioned on every cut cell (median 1e7 at k = 2), and the oracle is beyond 1e-12 on a fifth
+    of them (see judge_cut_cells).  `oper`: the product returns the solution with the constant of
     the negative side pinned to zero, the representative the binary128 side returns too -- compared
     directly; against the oracle (whose LDL^T leaves the kernel component e_0 + e_rbs to rounding) modulo that vector."""
     import cuthho_driver as cd
@@ -235,15 +235,12 @@ def test_interface_operators_match_oracle(asm, oracle, N, k, r, kappa):
           % (N, k, len(rows), np.median(cond), cond.max(), np.median(e_gpu), e_gpu.max(), np.median(e_orc), e_orc.max(),
              (e_gpu > TOL).sum(), (e_orc > TOL).sum(), e_oper.max()))
     assert np.all(e_stab < TOL)
-    assert np.all(e_gpu[cond < 1e5] < TOL)
-    assert np.all(e_gpu < TOL + 1e-15 * cond), np.max(e_gpu / (TOL + 1e-15 * cond))
-    big = np.maximum(e_gpu, e_orc) > 1e-13
-    gm = float(np.exp(np.mean(np.log(e_gpu[big] / e_orc[big])))) if big.any() else 1.0
-    print("   geometric mean of err_gpu / err_oracle over the %d cells beyond 1e-13: %.2f" % (int(big.sum()), gm))
-    assert gm <= 2.0, gm
-    assert np.all(e_oper < TOL + 1e-14 * cond) and np.all(e_oper_mod < TOL + 1e-13 * cond)
-    # (the pinned two-sided system is badly conditioned on EVERY cut cell -- median 1e7 at k = 2 --: the median error follows)
-    assert np.median(e_gpu) <= 2 * np.median(e_orc) + 1e-14 and np.median(e_gpu) < 1e-12
+    # the two-sided reconstruction system is formed, factored and solved in double-double (cut_interface_device.hpp): EVERY cut cell
+    # within 1e-12 of the binary128 evaluation -- data, and oper (the pinned representative) directly
+    assert np.all(e_gpu < TOL), (int((e_gpu >= TOL).sum()), e_gpu.max())
+    assert np.all(e_oper < TOL), e_oper.max()
+    # against the ORACLE's oper (double, pivoted LDL^T) only modulo the kernel vector and within the conditioning of ITS arithmetic
+    assert np.all(e_oper_mod < TOL + 1e-13 * cond)
 
 
 @pytest.mark.parametrize("N,k", [(10, 1), (20, 2)])

@@ -17,7 +17,7 @@ def one(cfg):
     for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", txt):
         name = m.group(1)
         t = re.search(r"CfgILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi\d+EEE(Li\d)?", name)
-        kind = "pre" if "cell_pre" in name else {"Li0": "lc", "Li1": "split", "Li2": "cond"}[t.group(6)]
+        kind = "pre" if "cell_pre" in name else "small" if "hho_small" in name else {"Li0": "lc", "Li1": "split", "Li2": "cond"}[t.group(6)]
         rows.append((tuple(int(x) for x in t.groups()[:5]), kind, int(m.group(3)), int(m.group(4)), int(m.group(2))))
     return rows
 
