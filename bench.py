@@ -222,14 +222,24 @@ class Pipeline:
         self._side = self._pin_out = self._pin_in = self._ev_pack = None
         asm, sz, dev = self.asm, self.sz, self.asm.device
         self.cut = bool(w.get("cut"))
+        whole = rows is None or (rows[0] == 0 and rows[1] == N)
         if self.cut:
-            asm.cut_preprocess(N, refsteps=4)                    # host preprocessing: outside the timed region
+            # host preprocessing (the whole mesh on every rank, the context keeps its slab): outside the timed region
+            asm.cut_preprocess(N, refsteps=4, rows=None if whole else rows)
             # (side-stream overlap of the cut cells' kernel, pa_context_set_cut_overlap: measured SLOWER here, 0.75 vs 0.69 ms
             # per step -- the persistent grid of the uncut cells' kernel holds the whole chip, the two only contend)
             asm.ctx.set_cut_overlap(bool(os.environ.get("PA_CUT_OVERLAP")))
-        elif w.get("perturb"):
+        elif w.get("perturb") and whole and mode != "C":
             self.mesh_keep = general_quad_mesh(torch, N, w["lo"], w["hi"], w["perturb"], dev)     # caller-owned device arrays
             asm.ctx.mesh_attach_device(self.mesh_keep[0].data_ptr(), (N + 1) * (N + 1), self.mesh_keep[1].data_ptr(), N * N)
+        elif w.get("perturb"):
+            # the generator's numbering (closed-form faces: condensed mode, slabs) with the displaced coordinates: every rank
+            # draws the same whole-mesh perturbation and keeps the node rows of its slab
+            asm.generate_mesh(N, N, w["lo"], w["hi"], rows=rows)
+            r0_, r1_ = (0, N) if rows is None else rows
+            pts = general_quad_mesh(torch, N, w["lo"], w["hi"], w["perturb"], dev)[0][r0_ * (N + 1):(r1_ + 1) * (N + 1)].contiguous()
+            asm.ctx.mesh_set_points(pts.data_ptr(), pts.shape[0])
+            torch.cuda.synchronize()
         else:
             asm.generate_mesh(N, N, w["lo"], w["hi"], rows=rows)
         self.n = asm.ncells
@@ -255,6 +265,12 @@ class Pipeline:
             self.b = torch.empty(max(ci.row_end - ci.row_begin, 1), **f64)
             self.halo_out = torch.empty((max(ci.halo_cells, 1), ci.halo_doubles), **f64)
             self.halo_in = torch.zeros((N, ci.halo_doubles), **f64) if ci.has_below else None
+            if self.cut:
+                nf_ = ci.nf
+                self.cut_lc = torch.empty((max(asm.ncut, 1), sz.msize, sz.msize), **f64)
+                self.cut_rhs = torch.empty((max(asm.ncut, 1), sz.cbs), **f64)
+                self.cut_Sp = torch.empty((max(asm.ncut, 1), nf_ * (nf_ + 1) // 2), **f64)
+                self.cut_g = torch.empty((max(asm.ncut, 1), nf_), **f64)
             if gather is not None:
                 world_, max_nnz, max_rows = gather
                 self.values = torch.zeros(max_nnz, **f64)          # (padded to the largest slab: all-gather wants equal counts)
@@ -297,7 +313,20 @@ class Pipeline:
             return
         ci, N = self.ci, self.N
         self._tick(i, "start")
-        asm.ctx.cell_rhs(w["cd"], w["dinc"], self.quad, w["fn"], 0, n, self.rhs.data_ptr(), None)
+        if self.cut:
+            # the cut cells first: operators (pa_cut_local_ops_batch), then the stand-alone condensation of their local matrices
+            # into packed records; the fused pass below runs the uncut formulas on every cell, pa_cut_merge_condensed replaces
+            # the cut cells' records before anything reads them (halo pack, fill)
+            if asm.ncut:
+                asm.ctx.cut_local_ops(w["fd"], asm.level_set, pa.capi.LOC_NEGATIVE, w["fn"], 2, None, None, None,
+                                      self.cut_lc.data_ptr(), self.cut_rhs.data_ptr(), None)
+                asm.ctx.static_condensation_packed(di, asm.ncut, self.cut_lc.data_ptr(), self.cut_rhs.data_ptr(),
+                                                   self.cut_Sp.data_ptr(), self.cut_g.data_ptr(), None)
+            self._tick(i, "cut")
+            asm.ctx.cut_uncut_rhs(w["cd"], pa.capi.LOC_NEGATIVE, w["fn"], self.rhs.data_ptr())
+            asm.ctx.cut_merge(w["fd"], pa.capi.LOC_NEGATIVE, None, self.cut_rhs.data_ptr(), None, self.rhs.data_ptr())     # zero outside the domain
+        else:
+            asm.ctx.cell_rhs(w["cd"], w["dinc"], self.quad, w["fn"], 0, n, self.rhs.data_ptr(), None)
         self._tick(i, "rhs")
         top = N if ci.halo_cells else 0
         nd = ci.cond_doubles
@@ -305,10 +334,15 @@ class Pipeline:
             # the slab's top cell row first: its packed top-face rows travel one slab up while the rest is computed
             f0 = n - top
             asm.ctx.condensed_ops(di, self.quad, self.stab, f0, top, self.rhs[f0:].data_ptr(), self.rec[f0:].data_ptr(), None)
+            if self.cut and asm.ncut:
+                asm.ctx.cut_merge_condensed(w["fd"], self.cut_Sp.data_ptr(), self.cut_g.data_ptr(), self.rec.data_ptr())
             asm.ctx.condensed_halo_pack(di, self.rec.data_ptr(), self.g.data_ptr(), self.halo_out.data_ptr())
         self._exchange_start()
         asm.ctx.condensed_ops(di, self.quad, self.stab, 0, n - top, self.rhs.data_ptr(), self.rec.data_ptr(), None)
         self._tick(i, "ops")
+        if self.cut and asm.ncut:
+            asm.ctx.cut_merge_condensed(w["fd"], self.cut_Sp.data_ptr(), self.cut_g.data_ptr(), self.rec.data_ptr())
+            self._tick(i, "merge")
         self._exchange_wait()
         self._tick(i, "exchange_wait")
         asm.ctx.condensed_csr_fill(di, self.rec.data_ptr(), self.g.data_ptr(), None if self.halo_in is None else self.halo_in.data_ptr(),
@@ -470,8 +504,8 @@ def main():
     mode = args.mode or ("L" if world == 1 else "C")
     w = WORKLOADS[workload]
     N = w["N"]
-    if (w.get("cut") or w.get("perturb")) and (world > 1 or mode != "L"):
-        raise SystemExit("the cut and the general-quadrilateral workloads are single-GPU, mode L")
+    if (w.get("cut") or w.get("perturb")) and mode == "A":
+        raise SystemExit("mode A runs on the generator mesh (assembler<Mesh>'s system of a fictitious-domain problem drops the cells outside the domain: not built)")
     if mode == "A" and world > 1:
         raise SystemExit("mode A (the reference's one-process \"Matrix assembly\" span) is single-GPU; several GPUs assemble the face-only system (mode C)")
     rehearsal = world > 1 and args.backend == "gloo"
@@ -562,7 +596,7 @@ def main():
     # mode's algorithmic bytes (cell rhs, operators + condensation, CSR fill): the bytes stand for the assembled face-face
     # system, which only exists after the fill.
     if mode == "C":
-        kern_ms = stages["rhs"] + stages["ops"] + stages["fill"]
+        kern_ms = stages["rhs"] + stages["ops"] + stages["fill"] + stages.get("cut", 0.0) + stages.get("merge", 0.0)
     else:
         kern_ms = stages["ops"] + stages.get("cut", 0.0) + stages.get("merge", 0.0)
     pipe.check()
@@ -580,6 +614,8 @@ def main():
             one_gpu = {"value": N * N / (t_ref / max(3, args.steps // 4)), "ms_per_step": t_ref / max(3, args.steps // 4) * 1e3}
             if mode == "C":
                 ref_sums = [float(ref.values.sum()), float(ref.values.abs().sum()), float(ref.b.sum()), float(ref.b.abs().sum())]
+            else:
+                ref_sums = [float(ref.lc.sum()), float(ref.lc.abs().sum()), float(ref.rhs.sum()), float(ref.rhs.abs().sum())]
             del ref
         dist.barrier()
         if mode == "C":
@@ -601,6 +637,17 @@ def main():
                 exchange_checked = (gather is None or gathered_ok) and all(abs(a - r) <= 1e-9 * max(abs(ref_sums[1 if i < 2 else 3]), 1e-300) for i, (a, r) in enumerate(zip(loc.tolist(), ref_sums)))
                 if not exchange_checked:      # reported in the line (and loudly here), not fatal: the timing is still a measurement
                     print("bench.py: the ranks' systems do NOT add up to the whole-mesh system: %r vs %r" % (loc.tolist(), ref_sums), file=sys.stderr, flush=True)
+
+        if mode == "L":
+            # no exchange in this mode; still: the slabs' local matrices and right-hand sides stacked are the whole mesh's
+            # (a slab that mis-read its node rows, or lost its cut cells, shows here)
+            loc = torch.tensor([float(pipe.lc.sum()), float(pipe.lc.abs().sum()), float(pipe.rhs.sum()), float(pipe.rhs.abs().sum())],
+                               dtype=torch.float64)
+            dist.all_reduce(loc, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                exchange_checked = all(abs(a - r) <= 1e-9 * max(abs(ref_sums[1 if i < 2 else 3]), 1e-300) for i, (a, r) in enumerate(zip(loc.tolist(), ref_sums)))
+                if not exchange_checked:
+                    print("bench.py: the slabs' local matrices do NOT add up to the whole mesh's: %r vs %r" % (loc.tolist(), ref_sums), file=sys.stderr, flush=True)
 
     names = ("rhs", "ops", "exchange_wait", "fill", "allgather", "cut", "merge")
     t = torch.tensor([elapsed, kern_ms] + [stages.get(k, 0.0) for k in names], dtype=torch.float64)

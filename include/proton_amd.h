@@ -125,6 +125,11 @@ int pa_mesh_generate(pa_context *ctx, size_t Nx, size_t Ny,
                      double min_x, double max_x, double min_y, double max_y,
                      size_t row_begin, size_t row_end);
 int pa_mesh_counts(pa_context *ctx, size_t *npoints, size_t *ncells);
+/* Replaces the coordinates of a mesh the context owns (pa_mesh_upload / pa_mesh_generate) and keeps its connectivity and
+ * numbering: msh.points edited in place (the commented-out node perturbation of convergence_test.cpp:176-187; a general
+ * quadrilateral mesh with the generator's closed-form face numbering, whole or as a slab of cell rows -- d_points then holds
+ * the slab's node rows row_begin .. row_end).  d_points: npoints x 2 doubles on the device, copied on the context's stream. */
+int pa_mesh_set_points(pa_context *ctx, const double *d_points, size_t npoints);
 
 /* ---- the hot path --------------------------------------------------------------------
  * For cells [first, first+n) of the uploaded mesh computes, per cell,
@@ -385,6 +390,16 @@ enum { PA_LOC_NEGATIVE = 0, PA_LOC_POSITIVE = 1, PA_LOC_ON_INTERFACE = 2 };     
  * search range") are returned as PA_ERR_INVALID_ARG with the text in pa_last_error(). */
 int pa_cut_preprocess(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
                       const pa_level_set *ls, int refsteps);
+/* The same for the slab of cell rows [row_begin, row_end) of a row partition ("cut cells are distributed
+ * by the same row rule"): the host preprocessing runs over the WHOLE mesh on every rank (deterministic: every rank tags and
+ * displaces the same nodes), the context keeps the slab -- its displaced node rows, the tags of its cells and its own cut
+ * cells, in ascending cell order.  Cell index 0 of the context is global cell row_begin * Nx (as pa_mesh_generate);
+ * pa_cut_query reports the slab's cells; pa_cut_query_tags still reports the whole mesh.  Everything per cell works on a
+ * slab (pa_cut_local_ops_batch, pa_cut_uncut_rhs_batch, pa_cut_merge, pa_cut_merge_condensed, pa_cut_interface_ops_batch,
+ * pa_cut_interface_uncut_batch); the interface_assembler's numbering (pa_interface_*) and pa_cut_agglo_query need a
+ * whole-mesh context and return PA_ERR_INVALID_ARG on a slab. */
+int pa_cut_preprocess_rows(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
+                           const pa_level_set *ls, int refsteps, size_t row_begin, size_t row_end);
 /* The agglomeration branch of the same preprocessing (`-A`, cuthho_square.cpp:2039-2044): no node
  * displacement.  The reference then only CLASSIFIES the cut cells (detect_cell_agglo_set); its
  * agglomerate_cells is dead code (cuthho_square.cpp:1525-1621).  All operators of this library
@@ -434,6 +449,10 @@ int pa_cut_uncut_rhs_batch(pa_context *ctx, int degree, int where, int fn, doubl
  * outside `where` is zeroed (cuthho_square.cpp:659-664). */
 int pa_cut_merge(pa_context *ctx, int face_deg, int where, const double *d_cut_lc, const double *d_cut_rhs,
                  double *d_lc, double *d_rhs);
+/* The merge of the condensed mode: the packed records of the cut cells -- pa_static_condensation_packed_batch of their local
+ * matrices and right-hand sides (pa_cut_local_ops_batch), d_cut_Sp ncut x nf(nf+1)/2 and d_cut_g ncut x nf -- replace the
+ * cut cells' records in d_cond (pa_condensed_ops_batch over all cells with the uncut formulas, n x (nf(nf+1)/2 + nf)). */
+int pa_cut_merge_condensed(pa_context *ctx, int face_deg, const double *d_cut_Sp, const double *d_cut_g, double *d_cond);
 
 /* ---- cutHHO two-sided interface problem (`cuthho_square -i`, run_cuthho_interface
  * cuthho_square.cpp:1625-1846).  hho_degree_info(face_deg + 1, face_deg) (:1662). */

@@ -310,10 +310,11 @@ class BatchAssembler:
         return out
 
     # ---- cutHHO fictitious domain (cuthho_square -f) ------------------------------------
-    def cut_preprocess(self, N, radius=0.35, center=(0.5, 0.5), refsteps=4):
-        """cuthho_square.cpp:2026-2052: mesh, circle level set, default (-D) preprocessing."""
+    def cut_preprocess(self, N, radius=0.35, center=(0.5, 0.5), refsteps=4, rows=None):
+        """cuthho_square.cpp:2026-2052: mesh, circle level set, default (-D) preprocessing.  rows = (row_begin, row_end): the
+        context keeps that slab of cell rows (pa_cut_preprocess_rows)."""
         self.level_set = capi.LevelSet(0, radius, center[0], center[1], 0.0)
-        self.ctx.cut_preprocess(N, N, self.level_set, refsteps)
+        self.ctx.cut_preprocess(N, N, self.level_set, refsteps, rows=rows)
         self.ncut, self.cell_loc, self.cut_index = self.ctx.cut_query()
         return self.ncut
 
@@ -354,6 +355,29 @@ class BatchAssembler:
         if overlap:
             self.ctx.set_cut_overlap(False)
         return out["lc"], rhs
+
+    def fictdom_condensed_ops(self, fd, where=capi.LOC_NEGATIVE, rhs_fn=capi.FN_SIN_SIN_RHS, bcs_fn=capi.FN_SIN_SIN_SOL):
+        """The same loop body in condensed mode: packed records [n, nf(nf+1)/2 + nf] of every cell of the context -- the fused
+        pass with the uncut formulas (fan quadrature, naive stabilization), the cut cells' records from the stand-alone
+        condensation of their cut operators (pa_static_condensation_packed_batch + pa_cut_merge_condensed).
+        -> (records, rhs [n, cbs])."""
+        cd = fd + 1
+        di, _ = capi.degree_info(cd, fd)
+        nf = 4 * (fd + 1)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        rhs = torch.empty((self.ncells, (cd + 1) * (cd + 2) // 2), **f64)
+        self.ctx.cut_uncut_rhs(cd, where, rhs_fn, rhs.data_ptr())
+        cut = None
+        if self.ncut:
+            cut = self.cut_local_ops(fd, where, rhs_fn, bcs_fn, want=("lc", "rhs"))
+            Sp = torch.empty((self.ncut, nf * (nf + 1) // 2), **f64)
+            g = torch.empty((self.ncut, nf), **f64)
+            self.ctx.static_condensation_packed(di, self.ncut, cut["lc"].data_ptr(), cut["rhs"].data_ptr(), Sp.data_ptr(), g.data_ptr(), None)
+        self.ctx.cut_merge(fd, where, None, None if cut is None else cut["rhs"].data_ptr(), None, rhs.data_ptr())
+        rec = self.condensed_ops(cd, fd, capi.QUAD_FAN, capi.STAB_NAIVE, rhs=rhs)
+        if self.ncut:
+            self.ctx.cut_merge_condensed(fd, Sp.data_ptr(), g.data_ptr(), rec.data_ptr())
+        return rec, rhs
 
     # ---- cutHHO two-sided interface problem (cuthho_square -i) ------------------------------
     def interface_local_ops(self, fd, kappa=(1.0, 1.0), eta=5.0, rhs_fn=capi.FN_SIN_SIN_RHS, want_oper=False):

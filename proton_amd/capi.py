@@ -40,6 +40,7 @@ EXPORTS = [
     "pa_comm_unique_id", "pa_comm_create", "pa_comm_destroy", "pa_comm_info", "pa_comm_last_error",
     "pa_comm_halo_exchange_start", "pa_comm_allgather_start", "pa_comm_allreduce_sum_start", "pa_comm_wait",
     "pa_comm_neighbour_exchange_start", "pa_conjugated_gradient_rows", "pa_comm_cg_transport", "pa_copy_to_host", "pa_copy_to_device", "pa_cut_uncut_rhs_batch",
+    "pa_mesh_set_points", "pa_cut_preprocess_rows", "pa_cut_merge_condensed",
 ]
 
 
@@ -176,6 +177,9 @@ def lib():
     L.pa_obstacle_expand_solution.argtypes = [vp, DegreeInfo, dp, dp, dp, vp, vp, vp, sz, dp, dp]
     L.pa_obstacle_take_local_data_batch.argtypes = [vp, DegreeInfo, sz, sz, dp, dp]
     L.pa_cut_preprocess.argtypes = [vp, sz, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(LevelSet), C.c_int]
+    L.pa_cut_preprocess_rows.argtypes = [vp, sz, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(LevelSet), C.c_int, sz, sz]
+    L.pa_cut_merge_condensed.argtypes = [vp, C.c_int, dp, dp, dp]
+    L.pa_mesh_set_points.argtypes = [vp, dp, sz]
     L.pa_cut_query.argtypes = [vp, C.POINTER(sz), vp, vp]
     L.pa_cut_local_ops_batch.argtypes = [vp, C.c_int, C.POINTER(LevelSet), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp]
     L.pa_cut_merge.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp]
@@ -496,8 +500,18 @@ class Context:
     def interface_cell_offsets(self, face_deg, out):
         self._ck(self._L.pa_interface_cell_offsets(self.h, face_deg, out), "pa_interface_cell_offsets")
 
-    def cut_preprocess(self, Nx, Ny, ls, refsteps, lo=(0.0, 0.0), hi=(1.0, 1.0)):
-        self._ck(self._L.pa_cut_preprocess(self.h, Nx, Ny, lo[0], hi[0], lo[1], hi[1], C.byref(ls), refsteps), "pa_cut_preprocess")
+    def cut_preprocess(self, Nx, Ny, ls, refsteps, lo=(0.0, 0.0), hi=(1.0, 1.0), rows=None):
+        if rows is None:
+            self._ck(self._L.pa_cut_preprocess(self.h, Nx, Ny, lo[0], hi[0], lo[1], hi[1], C.byref(ls), refsteps), "pa_cut_preprocess")
+        else:
+            self._ck(self._L.pa_cut_preprocess_rows(self.h, Nx, Ny, lo[0], hi[0], lo[1], hi[1], C.byref(ls), refsteps, rows[0], rows[1]),
+                     "pa_cut_preprocess_rows")
+
+    def mesh_set_points(self, d_points, npoints):
+        self._ck(self._L.pa_mesh_set_points(self.h, d_points, npoints), "pa_mesh_set_points")
+
+    def cut_merge_condensed(self, face_deg, cut_Sp, cut_g, cond):
+        self._ck(self._L.pa_cut_merge_condensed(self.h, face_deg, cut_Sp, cut_g, cond), "pa_cut_merge_condensed")
 
     def cut_preprocess_agglomeration(self, Nx, Ny, ls, refsteps, lo=(0.0, 0.0), hi=(1.0, 1.0)):
         self._ck(self._L.pa_cut_preprocess_agglomeration(self.h, Nx, Ny, lo[0], hi[0], lo[1], hi[1], C.byref(ls), refsteps),

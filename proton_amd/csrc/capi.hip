@@ -477,6 +477,16 @@ int pa_mesh_generate(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double
     return PA_OK;
 }
 
+int pa_mesh_set_points(pa_context *ctx, const double *d_points, size_t npoints)
+{
+    if (!ctx || !d_points) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (!ctx->d_points || !ctx->owns_mesh) return PA_ERR_NO_MESH;
+    if (npoints != ctx->npoints) return PA_ERR_INVALID_ARG;
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_points, d_points, npoints * 2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return PA_OK;
+}
+
 int pa_mesh_set_faces(pa_context *ctx, const uint32_t *cell_faces, const uint32_t *face_pts,
                       const uint8_t *face_is_dirichlet, size_t nfaces)
 {
@@ -1451,18 +1461,24 @@ int pa_condensed_expand_solution(pa_context *ctx, pa_degree_info di, const doubl
 
 // ---- cutHHO -----------------------------------------------------------------------------------
 static int cut_preprocess_impl(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
-                               const pa_level_set *ls, int refsteps, bool displace);
+                               const pa_level_set *ls, int refsteps, bool displace, size_t row_begin, size_t row_end);
 
 int pa_cut_preprocess(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
                       const pa_level_set *ls, int refsteps)
 {
-    return cut_preprocess_impl(ctx, Nx, Ny, min_x, max_x, min_y, max_y, ls, refsteps, true);
+    return cut_preprocess_impl(ctx, Nx, Ny, min_x, max_x, min_y, max_y, ls, refsteps, true, 0, Ny);
+}
+
+int pa_cut_preprocess_rows(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
+                           const pa_level_set *ls, int refsteps, size_t row_begin, size_t row_end)
+{
+    return cut_preprocess_impl(ctx, Nx, Ny, min_x, max_x, min_y, max_y, ls, refsteps, true, row_begin, row_end);
 }
 
 int pa_cut_preprocess_agglomeration(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
                                     const pa_level_set *ls, int refsteps)
 {
-    return cut_preprocess_impl(ctx, Nx, Ny, min_x, max_x, min_y, max_y, ls, refsteps, false);
+    return cut_preprocess_impl(ctx, Nx, Ny, min_x, max_x, min_y, max_y, ls, refsteps, false, 0, Ny);
 }
 
 int pa_cut_agglo_query(pa_context *ctx, int8_t *agglo_set, int32_t *neighbors)
@@ -1470,6 +1486,10 @@ int pa_cut_agglo_query(pa_context *ctx, int8_t *agglo_set, int32_t *neighbors)
     if (!ctx) return PA_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     if (!ctx->cut) return PA_ERR_NO_MESH;
+    if (ctx->ncells != ctx->cut->ncells()) {
+        ctx->last_error = "pa_cut_agglo_query: whole-mesh contexts only";
+        return PA_ERR_INVALID_ARG;
+    }
     if (agglo_set) {
         std::vector<int8_t> a;
         pa::classify_agglomeration(*ctx->cut, a);
@@ -1484,32 +1504,59 @@ int pa_cut_agglo_query(pa_context *ctx, int8_t *agglo_set, int32_t *neighbors)
 }
 
 static int cut_preprocess_impl(pa_context *ctx, size_t Nx, size_t Ny, double min_x, double max_x, double min_y, double max_y,
-                               const pa_level_set *ls, int refsteps, bool displace)
+                               const pa_level_set *ls, int refsteps, bool displace, size_t row_begin, size_t row_end)
 {
     if (!ctx || !ls || refsteps < 0 || refsteps > 10 || (ls->kind != 0 && ls->kind != 1)) return PA_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
-    int st = pa_mesh_generate(ctx, Nx, Ny, min_x, max_x, min_y, max_y, 0, Ny);
+    int st = pa_mesh_generate(ctx, Nx, Ny, min_x, max_x, min_y, max_y, row_begin, row_end);
     if (st != PA_OK) return st;
+    const bool whole = row_begin == 0 && row_end == Ny;
     pa::CutMeshHost *cm = new (std::nothrow) pa::CutMeshHost();
     if (!cm) return PA_ERR_INVALID_ARG;
     const pa::LevelSet L = {ls->kind, ls->radius, ls->alpha, ls->beta, ls->cut_y};
     try {
+        // the host preprocessing always sees the WHOLE mesh (a node is displaced by looking at its neighbours; the tags of a
+        // slab's faces and nodes are those of the whole mesh): every rank of a row partition runs the same deterministic pass
         pa::cut_preprocess(*cm, (uint32_t)Nx, (uint32_t)Ny, min_x, max_x, min_y, max_y, L, refsteps, displace);
     } catch (const std::exception &e) {
         ctx->last_error = std::string("cutHHO preprocessing: ") + e.what();
         delete cm;
         return PA_ERR_INVALID_ARG;
     }
+    const size_t nc_all = cm->ncells(), nc = ctx->ncells, base = ctx->cell_base;
+    if (!whole) {
+        // a slab keeps its own cut cells (global ids on the host, ids relative to the slab on the device) and their polylines
+        std::vector<uint32_t> mine;
+        std::vector<pa::P2d> ifc;
+        for (size_t r = 0; r < cm->cut_cells.size(); ++r) {
+            const uint32_t c = cm->cut_cells[r];
+            if (c < base || c >= base + nc) continue;
+            mine.push_back(c);
+            ifc.insert(ifc.end(), cm->iface.begin() + r * cm->nif, cm->iface.begin() + (r + 1) * cm->nif);
+        }
+        cm->cut_cells.swap(mine);
+        cm->iface.swap(ifc);
+        cm->cut_index.assign(nc_all, -1);
+        for (size_t r = 0; r < cm->cut_cells.size(); ++r) cm->cut_index[cm->cut_cells[r]] = (int32_t)r;
+    }
     release_cut(ctx);
     ctx->cut = cm;
-    const size_t nc = cm->ncells(), ncut = cm->cut_cells.size();
-    PA_HIP(ctx, hipMemcpyAsync(ctx->d_points, cm->pts.data(), cm->pts.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const size_t ncut = cm->cut_cells.size();
+    std::vector<uint32_t> local_ids(ncut);
+    for (size_t r = 0; r < ncut; ++r) local_ids[r] = cm->cut_cells[r] - (uint32_t)base;
+    // displaced coordinates of the slab's node rows row_begin .. row_end
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_points, cm->pts.data() + 2 * row_begin * (Nx + 1), ctx->npoints * 2 * sizeof(double),
+                               hipMemcpyHostToDevice, ctx->stream));
     PA_HIP(ctx, hipMalloc((void **)&ctx->d_cut_cells, (ncut ? ncut : 1) * sizeof(uint32_t)));
     PA_HIP(ctx, hipMalloc((void **)&ctx->d_cell_loc, nc));
     PA_HIP(ctx, hipMalloc((void **)&ctx->d_cut_index, nc * sizeof(int32_t)));
-    PA_HIP(ctx, hipMemcpyAsync(ctx->d_cut_cells, cm->cut_cells.data(), ncut * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    PA_HIP(ctx, hipMemcpyAsync(ctx->d_cell_loc, cm->cell_loc.data(), nc, hipMemcpyHostToDevice, ctx->stream));
-    PA_HIP(ctx, hipMemcpyAsync(ctx->d_cut_index, cm->cut_index.data(), nc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_cut_cells, local_ids.data(), ncut * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_cell_loc, cm->cell_loc.data() + base, nc, hipMemcpyHostToDevice, ctx->stream));
+    PA_HIP(ctx, hipMemcpyAsync(ctx->d_cut_index, cm->cut_index.data() + base, nc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (!whole) {                // the interface_assembler's tables number the whole mesh: whole-mesh contexts only
+        PA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return PA_OK;
+    }
     // interface_assembler tables (cuthho_square.cpp:1142-1178): cut cells / cut faces own two blocks, so the
     // first block of an element = its plain (compressed) index + the number of cut elements before it
     const size_t nf = cm->nfaces();
@@ -1552,8 +1599,9 @@ int pa_cut_query(pa_context *ctx, size_t *ncut, int8_t *cell_location, int32_t *
     (void)hipSetDevice(ctx->device);
     if (!ctx->cut) return PA_ERR_NO_MESH;
     if (ncut) *ncut = ctx->cut->cut_cells.size();
-    if (cell_location) std::memcpy(cell_location, ctx->cut->cell_loc.data(), ctx->cut->ncells());
-    if (cut_index) std::memcpy(cut_index, ctx->cut->cut_index.data(), ctx->cut->ncells() * sizeof(int32_t));
+    // (the cells of the context: of a slab of pa_cut_preprocess_rows, its own rows)
+    if (cell_location) std::memcpy(cell_location, ctx->cut->cell_loc.data() + ctx->cell_base, ctx->ncells);
+    if (cut_index) std::memcpy(cut_index, ctx->cut->cut_index.data() + ctx->cell_base, ctx->ncells * sizeof(int32_t));
     return PA_OK;
 }
 
@@ -1741,7 +1789,7 @@ int pa_cut_uncut_rhs_batch(pa_context *ctx, int degree, int where, int fn, doubl
     int nqp = 0;
     const int st = rhs_quadrature(ctx, qdeg, PA_QUAD_FAN, &nqp);
     if (st != PA_OK) return st;
-    const size_t n = ctx->cut->ncells();
+    const size_t n = ctx->ncells;
     if (n == 0) return PA_OK;
     return launch_rhs<pa::QUAD_FAN>(ctx, degree, qdeg, nqp, fn, nullptr, 0, n, d_rhs, ctx->d_cell_loc, where);
 }
@@ -1753,7 +1801,7 @@ int pa_cut_merge(pa_context *ctx, int face_deg, int where, const double *d_cut_l
     (void)hipSetDevice(ctx->device);
     if (!ctx->cut) return PA_ERR_NO_MESH;
     const int cbs = pa::P2(face_deg + 1), ms = cbs + 4 * (face_deg + 1);
-    const uint32_t nc = (uint32_t)ctx->cut->ncells();
+    const uint32_t nc = (uint32_t)ctx->ncells;
     const uint32_t ncut = (uint32_t)ctx->cut->cut_cells.size();
     if (ctx->side_pending) {                              // the cut cells' kernel ran on the side stream
         PA_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
@@ -1767,6 +1815,25 @@ int pa_cut_merge(pa_context *ctx, int face_deg, int where, const double *d_cut_l
     if (ncut)
         hipLaunchKernelGGL(pa::cut_merge_cells_kernel, dim3(ncut), dim3(64), 0, ctx->stream, ncut, ctx->d_cut_cells, ms * ms, cbs, d_cut_lc,
                            d_cut_rhs, d_lc, d_rhs);
+    PA_HIP(ctx, hipGetLastError());
+    return PA_OK;
+}
+
+int pa_cut_merge_condensed(pa_context *ctx, int face_deg, const double *d_cut_Sp, const double *d_cut_g, double *d_cond)
+{
+    if (!ctx || !d_cond || face_deg < 0 || face_deg > 2) return PA_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (!ctx->cut) return PA_ERR_NO_MESH;
+    const uint32_t ncut = (uint32_t)ctx->cut->cut_cells.size();
+    if (ncut == 0) return PA_OK;
+    if (!d_cut_Sp || !d_cut_g) return PA_ERR_INVALID_ARG;
+    if (ctx->side_pending) {                              // the cut cells' kernel ran on the side stream
+        PA_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+        ctx->side_pending = false;
+    }
+    const int nf = 4 * (face_deg + 1), ntri = nf * (nf + 1) / 2;
+    hipLaunchKernelGGL(pa::cut_merge_condensed_kernel, dim3(ncut), dim3(64), 0, ctx->stream, ncut, ctx->d_cut_cells, ntri, nf, d_cut_Sp, d_cut_g,
+                       d_cond);
     PA_HIP(ctx, hipGetLastError());
     return PA_OK;
 }
@@ -1881,6 +1948,10 @@ int pa_interface_assembler_query(pa_context *ctx, int face_deg, pa_interface_inf
     if (!ctx || !out || face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     if (!ctx->cut) return PA_ERR_NO_MESH;
+    if (!ctx->d_if_cell_table) {
+        ctx->last_error = "the interface_assembler's numbering covers the whole mesh: not available on a slab of pa_cut_preprocess_rows";
+        return PA_ERR_INVALID_ARG;
+    }
     out->num_all_cells = ctx->if_num_all_cells;
     out->num_other_faces = ctx->if_num_other_faces;
     out->system_size = (uint64_t)pa::P2(face_deg + 1) * ctx->if_num_all_cells + (uint64_t)(face_deg + 1) * ctx->if_num_other_faces;
@@ -1897,6 +1968,10 @@ int pa_interface_triplets_batch(pa_context *ctx, int face_deg, const double *d_l
     (void)hipSetDevice(ctx->device);
     if (face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_DEGREE;
     if (!ctx->cut || !ctx->d_cell_faces) return PA_ERR_NO_MESH;
+    if (!ctx->d_if_cell_table) {
+        ctx->last_error = "the interface_assembler's numbering covers the whole mesh: not available on a slab of pa_cut_preprocess_rows";
+        return PA_ERR_INVALID_ARG;
+    }
     const size_t ncut = ctx->cut->cut_cells.size();
     if (ncut && (!d_lc_cut || !d_rows_cut || !d_cols_cut || !d_vals_cut || !d_rhs_rows_cut || !d_rhs_vals_cut)) return PA_ERR_INVALID_ARG;
     pa_interface_info info;
@@ -1924,6 +1999,10 @@ int pa_interface_cell_offsets(pa_context *ctx, int face_deg, int64_t *d_offsets)
     if (!ctx || !d_offsets || face_deg < 0 || face_deg > 3) return PA_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     if (!ctx->cut) return PA_ERR_NO_MESH;
+    if (!ctx->d_if_cell_table) {
+        ctx->last_error = "the interface_assembler's numbering covers the whole mesh: not available on a slab of pa_cut_preprocess_rows";
+        return PA_ERR_INVALID_ARG;
+    }
     const pa::CutMeshHost &cm = *ctx->cut;
     const size_t nc = cm.ncells();
     const int64_t cbs = pa::P2(face_deg + 1);

@@ -714,6 +714,17 @@ __global__ __launch_bounds__(64) void cut_merge_cells_kernel(uint32_t ncut, cons
         for (int e = threadIdx.x; e < cbs; e += 64) rhs[c * (size_t)cbs + e] = cut_rhs[cc * (size_t)cbs + e];
 }
 
+// condensed mode: the cut cells' packed records [upper triangle of S | g] into the cell-major record array
+__global__ __launch_bounds__(64) void cut_merge_condensed_kernel(uint32_t ncut, const uint32_t *cut_cells, int ntri, int nf, const double *cut_Sp,
+                                                                const double *cut_g, double *cond)
+{
+    const size_t cc = blockIdx.x;
+    if (cc >= ncut) return;
+    double *dst = cond + (size_t)cut_cells[cc] * (size_t)(ntri + nf);
+    for (int e = threadIdx.x; e < ntri; e += 64) dst[e] = cut_Sp[cc * (size_t)ntri + e];
+    for (int e = threadIdx.x; e < nf; e += 64) dst[ntri + e] = cut_g[cc * (size_t)nf + e];
+}
+
 __global__ __launch_bounds__(256) void cut_zero_rhs_kernel(size_t total, uint32_t cbs, const int8_t *cell_loc, int where, double *rhs)
 {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;

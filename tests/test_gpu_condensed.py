@@ -202,18 +202,32 @@ def test_condensed_solve_equals_uncondensed(asm, N, cd, fd):
     assert float((loc - loc_ref).abs().max()) < 1e-9 * scale
 
 
-@pytest.mark.parametrize("N,cd,fd,parts", [(8, 2, 1, (0, 3, 8)), (9, 3, 2, (0, 2, 5, 9)), (6, 4, 3, (0, 1, 2, 6))])
-def test_condensed_slabs_equal_whole_mesh(asm, N, cd, fd, parts):
+@pytest.mark.parametrize("N,cd,fd,parts,perturb", [(8, 2, 1, (0, 3, 8), 0.0), (9, 3, 2, (0, 2, 5, 9), 0.0), (6, 4, 3, (0, 1, 2, 6), 0.0),
+                                                   (9, 3, 2, (0, 4, 9), 0.1), (7, 2, 1, (0, 1, 5, 7), 0.1)])
+def test_condensed_slabs_equal_whole_mesh(asm, N, cd, fd, parts, perturb):
     """Row partition of the face-only system: every slab assembles the rows it owns from its own cells' records plus
     the packed top-face rows of the slab below (the whole exchange of a step); stacked, the slabs' CSR rows and
-    right-hand sides are the whole-mesh system bit for bit."""
+    right-hand sides are the whole-mesh system bit for bit.  perturb: general quadrilaterals -- the generator's numbering with
+    displaced interior nodes (pa_mesh_set_points: every slab takes its node rows of the same whole-mesh displacement)."""
     import torch
     import proton_amd as pa
     from proton_amd.batch import BatchAssembler
+    rng = np.random.default_rng(12345)
+    shift = rng.uniform(-perturb / N, perturb / N, size=(N + 1, N + 1, 2))
+    shift[0, :] = shift[-1, :] = 0.0
+    shift[:, 0] = shift[:, -1] = 0.0
+    xs = np.linspace(0.0, 1.0, N + 1)
+    pts_all = np.stack(np.meshgrid(xs, xs, indexing="xy"), axis=-1) + shift          # [j][i] = (x_i, y_j)
 
     def slab(rows):
         a = BatchAssembler(0)
         a.generate_mesh(N, N, rows=rows)
+        if perturb:
+            p = torch.from_numpy(np.ascontiguousarray(pts_all[rows[0]:rows[1] + 1].reshape(-1, 2))).to(a.device)
+            a.ctx.mesh_set_points(p.data_ptr(), p.shape[0])
+            a.synchronize()
+            with pytest.raises(Exception):
+                a.ctx.mesh_set_points(p.data_ptr(), p.shape[0] + 1)
         rhs = a.cell_rhs(cd, pa.capi.FN_SIN_SIN_RHS, pa.QUAD_TENSOR)
         g = a.dirichlet_data(fd, pa.capi.FN_SIN_SIN_SOL)
         rec = a.condensed_ops(cd, fd, pa.QUAD_TENSOR, pa.STAB_FANCY, rhs=rhs)

@@ -422,3 +422,76 @@ def test_uncut_rhs_of_the_domain_only_equals_rhs_then_zeroing(asm, N, k):
     asm.ctx.cut_merge(k, pa.capi.LOC_NEGATIVE, cut["lc"].data_ptr(), cut["rhs"].data_ptr(), None, rhs.data_ptr())
     asm.synchronize()
     assert torch.equal(rhs, rhs_ref)
+
+
+@pytest.mark.parametrize("N,k,world", [(40, 1, 3), (64, 2, 4), (23, 2, 5)])
+def test_cut_cells_under_the_row_partition_equal_the_whole_mesh(asm, N, k, world):
+    """"cut cells (config 3) are distributed by the same row rule".  pa_cut_preprocess_rows: every slab of a
+    row partition, one after the other on this GPU, produces bit for bit the rows of the whole mesh's merged local matrices and
+    right-hand sides (uncut cells AND cut cells on the displaced nodes), its tags are the whole mesh's, and the slabs' cut cells
+    add up to the whole mesh's."""
+    import torch
+    from proton_amd.batch import BatchAssembler
+    from proton_amd.partition import row_partition
+    asm.cut_preprocess(N, refsteps=4)
+    lc_all, rhs_all = asm.fictdom_local_ops(k)
+    ncut_all, loc_all, idx_all = asm.ncut, asm.cell_loc.copy(), asm.cut_index.copy()
+    assert ncut_all > 0
+    slab = BatchAssembler(0)
+    seen = 0
+    for rank in range(world):
+        r0, r1 = row_partition(N, world, rank)
+        slab.cut_preprocess(N, refsteps=4, rows=(r0, r1))
+        assert slab.ncells == (r1 - r0) * N
+        assert np.array_equal(slab.cell_loc, loc_all[r0 * N:r1 * N])
+        mine = idx_all[r0 * N:r1 * N]
+        assert np.array_equal(slab.cut_index >= 0, mine >= 0)
+        assert np.array_equal(slab.cut_index[mine >= 0], mine[mine >= 0] - seen)          # ascending cell order, renumbered from 0
+        seen += slab.ncut
+        lc, rhs = slab.fictdom_local_ops(k)
+        assert torch.equal(lc, lc_all[r0 * N:r1 * N]) and torch.equal(rhs, rhs_all[r0 * N:r1 * N])
+        # whole-mesh numberings are refused on a slab
+        with pytest.raises(Exception):
+            slab.ctx.cut_agglo_query()
+    assert seen == ncut_all
+
+
+@pytest.mark.parametrize("N,k", [(20, 1), (32, 2)])
+def test_cut_workload_in_condensed_mode(asm, N, k):
+    """Config 3 in the condensed mode: the record of a cut cell is the stand-alone condensation (pa_static_condensation_packed_batch)
+    of its cut operator and cut right-hand side, bit for bit; every other record is the fused pass's (fan quadrature, naive
+    stabilization, right-hand side of the domain's cells only), untouched by the merge; and the records agree with the
+    condensation of the merged local matrices of mode L within rounding."""
+    import torch
+    from proton_amd import capi
+    asm.cut_preprocess(N, refsteps=4)
+    cd, fd = k + 1, k
+    di, _ = capi.degree_info(cd, fd)
+    nf = 4 * (fd + 1)
+    rec, rhs = asm.fictdom_condensed_ops(fd)
+    lc_all, rhs_all = asm.fictdom_local_ops(fd)
+    assert torch.equal(rhs, rhs_all)
+    S, g, _, info = asm.static_condensation(cd, fd, lc_all, rhs_all)
+    assert int(info.abs().max()) == 0
+    iu = torch.triu_indices(nf, nf)
+    # column-packed upper triangle: entry (i, j), i <= j, at j (j + 1) / 2 + i; S is [n, col, row]
+    pos = (iu[1] * (iu[1] + 1) // 2 + iu[0]).to(rec.device)
+    want = torch.empty_like(rec)
+    want[:, pos] = S[:, iu[1], iu[0]]
+    want[:, nf * (nf + 1) // 2:] = g
+    cut = torch.from_numpy(asm.cut_index >= 0).to(rec.device)
+    assert int(cut.sum()) == asm.ncut > 0
+    ntri = nf * (nf + 1) // 2
+    eS = (rec[:, :ntri] - want[:, :ntri]).abs().amax(dim=1) / want[:, :ntri].abs().amax(dim=1)
+    gscale = torch.maximum(want[:, ntri:].abs().amax(dim=1), rhs_all.abs().amax(dim=1)).clamp_min(1e-300)
+    eg = (rec[:, ntri:] - want[:, ntri:]).abs().amax(dim=1) / gscale
+    assert float(eS.max()) < 1e-11 and float(eg.max()) < 1e-11, (float(eS.max()), float(eg.max()))
+    # cut cells: the stand-alone condensation of the cut operators, bit for bit (same kernel, same inputs)
+    cut_lc, cut_rhs = lc_all[cut].contiguous(), rhs_all[cut].contiguous()
+    Sp = torch.empty((asm.ncut, ntri), dtype=torch.float64, device=rec.device)
+    gp = torch.empty((asm.ncut, nf), dtype=torch.float64, device=rec.device)
+    asm.ctx.static_condensation_packed(di, asm.ncut, cut_lc.data_ptr(), cut_rhs.data_ptr(), Sp.data_ptr(), gp.data_ptr(), None)
+    assert torch.equal(rec[cut][:, :ntri], Sp) and torch.equal(rec[cut][:, ntri:], gp)
+    # the merge touches the cut cells only
+    plain = asm.condensed_ops(cd, fd, capi.QUAD_FAN, capi.STAB_NAIVE, rhs=rhs)
+    assert torch.equal(plain[~cut], rec[~cut]) and not torch.equal(plain[cut], rec[cut])
