@@ -21,6 +21,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "cut_host.hpp"
 #include "dd_arith.hpp"
@@ -55,6 +56,13 @@ __device__ __forceinline__ double ipow(double x, int n)
     return v;
 }
 
+// 1: the quadrature points a stage starts from are loaded under the stage before it.  Measured (A/B of tagged builds in one call,
+// config 3): 0.0975 ms with, 0.0955 ms without -- in a stream of launches the lists sit in L2 and the registers the early loads
+// hold cost more than their latency.  Kept as a switch, off.
+#ifndef PA_CUT_PREFETCH
+#define PA_CUT_PREFETCH 0
+#endif
+
 template <int FD, bool DD = true>
 // (a block is one wavefront: wave_sync() orders its LDS traffic without the wait for outstanding loads / stores that
 // __syncthreads() adds -- the quadrature lists of the next chunk stay in flight)
@@ -69,12 +77,10 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
     constexpr int ROWW = imax(2 * RBS, PW);
     constexpr int oTPHI = oOP + W * RBS * MS, oTDN = oTPHI + CH * RBS, oTW = oTPHI + CH * ROWW;
     constexpr int oFB = oTW + CH, oMF = oFB + NFPT * FBS, oTR = oMF + 4 * FBS * FBS, oPT = oTR + NF * CBS, oDATA = oPT + NF * CBS, oEND = oDATA + MS * MS;
-    // DD tables on the point table [oTPHI, oTPHI + CH ROWW): stage B, chunks of CHB points: phi (CHB RBS pairs), then dn; stage C:
+    // DD tables on the point table [oTPHI, oTPHI + CH ROWW): stage B: the interface moments; stage C:
     // phi and w dn of the NFPT face points, then their face-basis values
-    constexpr int CHB = imin(64, (CH * ROWW) / (6 * RBS));     // three tables of (hi, lo) pairs per point: 21 points at k = 2
-    constexpr int oBPH = oTPHI, oBDN = oTPHI + 2 * CHB * RBS, oBG = oBDN + 2 * CHB * RBS;
     constexpr int oCPH = oTPHI, oCDN = oTPHI + 2 * NFPT * RBS, oCFB = oCDN + 2 * NFPT * RBS;
-    static_assert(!DD || (6 * CHB * RBS <= CH * ROWW && oCFB + 2 * NFPT * FBS <= oTPHI + CH * ROWW && CHB <= CH && CHB >= 1), "the double-double tables fit the point table");
+    static_assert(!DD || oCFB + 2 * NFPT * FBS <= oTPHI + CH * ROWW, "the double-double tables fit the point table");
     __shared__ __attribute__((aligned(16))) double S[oEND];
     const int l = threadIdx.x;
 
@@ -168,9 +174,12 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
             }
         }
         int bad = 0;
+        // loads of stages F and H issued early by the double-double path (see stage E)
+        double f_x = 0.0, f_y = 0.0, f_w = 0.0, h_x = 0.0, h_y = 0.0, h_w = 0.0;
+        int f_n = 0;
         if constexpr (DD) {
         // =========== stages A-E in double-double (see the head of the file) ===========
-        static_assert(RBS * (RBS + 1) / 2 <= 64 && MS <= 64 && NFPT <= 64 && CHB <= 64, "one lane per pair / column / point");
+        static_assert(RBS * (RBS + 1) / 2 <= 64 && MS <= 64 && NFPT <= 64, "one lane per pair / column / point");
         // exponents of the monomials as compile-time tables (graded ordering, bases.hpp:114-128)
         // ---- A: moments  sum_q w_q bx^p by^r  over the cut cell's quadrature (cuthho_square.cpp:336-341): one lane per POINT (the
         // points of the list dealt out round robin), 28 double-double accumulators per lane, then a butterfly over the lanes
@@ -183,8 +192,14 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
             for (int m = 0; m < NMOM; ++m) macc[m] = dd_from(0.0);
 #pragma unroll
             for (int m = 0; m < CBS; ++m) racc[m] = 0.0;
+            // (the next point of a lane is loaded while the current one is worked on: a wavefront alone on its SIMD has nothing else
+            // to cover a load's round trip to L2 / HBM with, and every stage of this kernel used to start with one)
+            double nxt_x = 0.0, nxt_y = 0.0, nxt_w = 0.0;
+            if (PA_CUT_PREFETCH && c0 + l < c1) { nxt_x = a.cell_xyw[3 * (c0 + l)]; nxt_y = a.cell_xyw[3 * (c0 + l) + 1]; nxt_w = a.cell_xyw[3 * (c0 + l) + 2]; }
             for (uint32_t q = c0 + l; q < c1; q += 64) {
-                const double x = a.cell_xyw[3 * q], y = a.cell_xyw[3 * q + 1], w = a.cell_xyw[3 * q + 2];
+                const double x = PA_CUT_PREFETCH ? nxt_x : a.cell_xyw[3 * q], y = PA_CUT_PREFETCH ? nxt_y : a.cell_xyw[3 * q + 1];
+                const double w = PA_CUT_PREFETCH ? nxt_w : a.cell_xyw[3 * q + 2];
+                if (PA_CUT_PREFETCH && q + 64 < c1) { nxt_x = a.cell_xyw[3 * (q + 64)]; nxt_y = a.cell_xyw[3 * (q + 64) + 1]; nxt_w = a.cell_xyw[3 * (q + 64) + 2]; }
                 const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
                 dd pbx[NPW], pby[NPW];                  // w bx^e, by^e
                 pbx[0] = dd_from(w); pby[0] = dd_from(1.0);
@@ -203,24 +218,24 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
                         for (int r = 0; r <= k; ++r) racc[k * (k + 1) / 2 + r] += fv * (pbx[k - r].hi * pby[r].hi);
                 }
             }
-#pragma unroll
-            for (int m = 0; m < NMOM; ++m) {
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const dd o = dd{__shfl_xor(macc[m].hi, off), __shfl_xor(macc[m].lo, off)};
-                    macc[m] = dd_add_fast(macc[m], o);
-                }
-                if (l == m) dd_store(S + oMOM + 2 * m, macc[m]);
+            // sums over the lanes: a butterfly that halves the values a lane carries at every level (dd_arith.hpp): 29 exchanges
+            // for the 28 moments where the plain butterfly makes 168
+            {
+                dd tot; bool ok = true;
+                const int m = lanes_transpose_reduce<NMOM, 32>(macc, l, dd_from(0.0), [](dd x, dd y) { return dd_add_fast(x, y); },
+                                                               [](dd x, int off) { return dd_shfl_xor(x, off); }, tot, ok);
+                if (ok) dd_store(S + oMOM + 2 * m, tot);      // (the lanes that end with the same entry hold the same sum)
             }
             if (a.rhs != nullptr) {
-#pragma unroll
-                for (int m = 0; m < CBS; ++m) {
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) racc[m] += __shfl_xor(racc[m], off);
-                    if (l == m) rhs_acc = racc[m];
-                }
+                double tot; bool ok = true;
+                const int m = lanes_transpose_reduce<CBS, 32>(racc, l, 0.0, [](double x, double y) { return x + y; },
+                                                              [](double x, int off) { return __shfl_xor(x, off); }, tot, ok);
+                // lane m of the wavefront keeps the volume part of mode m for stage H
+                S[oTW + (ok ? m : CH - 1)] = tot;       // (scratch: the point weights' row is dead in the double-double path until H)
             }
         }
+        wave_sync();
+        if (a.rhs != nullptr && l < CBS) rhs_acc = S[oTW + l];
         wave_sync();
         PA_CUT_TICK(1);
         const dd ih2 = two_prod(ih, ih);
@@ -234,67 +249,127 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
             dd_store(S + oST + 2 * ((e % RBS) + (e / RBS) * LD), dd_mul(v, ih2));
         }
         wave_sync();
-        // the scaled monomials and their gradients at a point, double-double from the double coordinates
-        auto basis_dd = [&](double bx, double by, dd (&phi)[RBS], dd (&gx)[RBS], dd (&gy)[RBS]) {
-            dd pbx[RD + 1], pby[RD + 1];
+        // the scaled monomials and their gradients at a point, double-double from the double coordinates:
+        // one monomial of the same basis with RUN-TIME exponents (a lane's share of a point's monomials): the powers are picked from
+        // the registers by selects, never by a dynamic index (which would send the arrays to scratch memory)
+        auto pick_dd = [&](const dd (&arr)[RD + 1], int i) {
+            dd v = arr[0];
+#pragma unroll
+            for (int e = 1; e <= RD; ++e) { v.hi = i == e ? arr[e].hi : v.hi; v.lo = i == e ? arr[e].lo : v.lo; }
+            return v;
+        };
+        auto powers_dd = [&](double bx, double by, dd (&pbx)[RD + 1], dd (&pby)[RD + 1]) {
             pbx[0] = dd_from(1.0); pby[0] = dd_from(1.0);
 #pragma unroll
             for (int e = 1; e <= RD; ++e) { pbx[e] = dd_mul_d(pbx[e - 1], bx); pby[e] = dd_mul_d(pby[e - 1], by); }
-            int m = 0;
-#pragma unroll
-            for (int kk = 0; kk <= RD; ++kk)
-#pragma unroll
-                for (int ii = 0; ii <= kk; ++ii, ++m) {
-                    const int p_ = kk - ii, r_ = ii;                                    // (px, py) = (k - i, i)
-                    phi[m] = dd_mul(pbx[p_], pby[r_]);
-                    gx[m] = p_ == 0 ? dd_from(0.0) : dd_mul(dd_mul(pbx[p_ > 0 ? p_ - 1 : 0], pby[r_]), two_prod((double)p_, ih));
-                    gy[m] = r_ == 0 ? dd_from(0.0) : dd_mul(dd_mul(pbx[p_], pby[r_ > 0 ? r_ - 1 : 0]), two_prod((double)r_, ih));
-                }
+        };
+        auto basis_dd_one = [&](const dd (&pbx)[RD + 1], const dd (&pby)[RD + 1], int m, dd &phi, dd &gx, dd &gy) {
+            int p_, r_;
+            mono_exps(m, p_, r_);
+            const dd xp = pick_dd(pbx, p_), yr = pick_dd(pby, r_);
+            const dd xp1 = pick_dd(pbx, p_ > 0 ? p_ - 1 : 0), yr1 = pick_dd(pby, r_ > 0 ? r_ - 1 : 0);
+            phi = dd_mul(xp, yr);
+            gx = dd_mul(dd_mul(xp1, yr), two_prod((double)p_, ih));           // (p = 0: the factor is zero)
+            gy = dd_mul(dd_mul(xp, yr1), two_prod((double)r_, ih));
         };
         PA_CUT_TICK(2);
-        // ---- B: Nitsche terms on the interface (cuthho_square.cpp:347-360): chunks of CHB points staged by their lanes, one lane per
-        // unordered pair (i, j) of the symmetric matrix accumulates  w (eta/h_T phi_i phi_j - phi_i dn_j - dn_i phi_j)
+        constexpr int LPC = 64 / NFPT;                     // stage C: lanes per face point (3 with the 20 slots)
+        static_assert(LPC >= 1, "a lane per face point");
+        const int c_pt = imin(l / LPC, NFPT - 1);
+        const double *c_src;
+        double c_x, c_y, c_w;
+        int c_n;
+        // ---- B: Nitsche terms on the interface (cuthho_square.cpp:347-360):  sum_q w (eta/h_T phi_i phi_j - phi_i dn_j - dn_i phi_j).
+        // The basis functions are monomials bx^p by^r, so with P = p_i + p_j, R = r_i + r_j the entry is
+        //     eta/h_T M(P, R) - ih ( P Mx(P - 1, R) + R My(P, R - 1) ),
+        // M, Mx, My the moments of the interface measure w, w n_x, w n_y: 28 + 21 + 21 sums at k = 2 instead of the 55 pairs' two
+        // products per point, formed like the cell moments of stage A (a lane per point, the transposed butterfly), three passes over
+        // the points so that one pass's accumulators fit the registers.  (Staging phi, w dn and w (eta/h phi - dn) per point and
+        // summing the pairs' terms point by point was 41 k of the kernel's 157 k clocks.)
         {
             const uint32_t i0 = a.il_off[cc], i1 = a.il_off[cc + 1];
-            int pi_ = 0, pj_ = 0;                                                       // this lane's pair, i <= j
-            {
-                int jj = 0;
-                while ((jj + 1) * (jj + 2) / 2 <= l && jj + 1 < RBS) ++jj;
-                pj_ = jj; pi_ = l - jj * (jj + 1) / 2;
-            }
-            const bool has_pair = l < RBS * (RBS + 1) / 2;
-            dd nacc = dd_from(0.0);
-            for (uint32_t base = i0; base < i1; base += CHB) {
-                const uint32_t q = base + l;
-                if (l < CHB && q < i1) {
-                    const double x = a.il_xyw[3 * q], y = a.il_xyw[3 * q + 1];
+            constexpr int DM = 2 * RD, NM1 = P2(DM - 1);
+            constexpr int oIM = oTPHI, oIX = oIM + 2 * NMOM, oIY = oIX + 2 * NM1;
+            static_assert(2 * (NMOM + 2 * NM1) <= CH * ROWW, "the interface moments fit the point table");
+            // (... and the face point stage C will want, so that its round trip runs under this stage: the slots of a face without
+            // points exist and hold zeros, the loads do not wait for the count)
+            auto load_c = [&]() {
+                c_src = a.fl_xyw + (((size_t)cc * 4 + c_pt / FACE_SLOTS) * FACE_SLOTS + c_pt % FACE_SLOTS) * 3;
+                c_x = c_src[0]; c_y = c_src[1]; c_w = c_src[2];
+                c_n = a.fl_cnt[cc * 4 + c_pt / FACE_SLOTS];
+            };
+            if (PA_CUT_PREFETCH) load_c();
+            // (the lane's point of the first 64 -- normally all there are -- and its normal: loaded and formed once for the passes)
+            const bool in0 = i0 + l < i1;
+            const double x0 = in0 ? a.il_xyw[3 * (i0 + l)] : barx, y0 = in0 ? a.il_xyw[3 * (i0 + l) + 1] : bary;
+            const double w0 = in0 ? a.il_xyw[3 * (i0 + l) + 2] : 0.0;
+            double nx0, ny0;
+            a.ls.normal(x0, y0, nx0, ny0);                                  // not flipped for the positive side (:352-355)
+            // one pass: the moments of total degree K0 .. K1 of measure KIND (0: w, 1: w n_x, 2: w n_y)
+            auto iface_moments = [&](auto kind_c, auto k0_c, auto k1_c, double *dst) {
+                constexpr int KIND = decltype(kind_c)::value, K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value;
+                constexpr int B0 = K0 * (K0 + 1) / 2, NM = P2(K1) - B0;
+                dd acc[NM];
+                bool first = true;
+                for (uint32_t q0 = i0; q0 < i1; q0 += 64) {
+                    const uint32_t q = q0 + l;
+                    const bool in = q < i1;
+                    double x = x0, y = y0, w = w0, nx = nx0, ny = ny0;
+                    if (q0 != i0) {
+                        x = in ? a.il_xyw[3 * q] : barx; y = in ? a.il_xyw[3 * q + 1] : bary; w = in ? a.il_xyw[3 * q + 2] : 0.0;
+                        if (KIND != 0) a.ls.normal(x, y, nx, ny);
+                    }
                     const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
-                    double nx, ny;
-                    a.ls.normal(x, y, nx, ny);                    // not flipped for the positive side (:352-355)
-                    dd phi[RBS], gx[RBS], gy[RBS];
-                    basis_dd(bx, by, phi, gx, gy);
-                    const double w = a.il_xyw[3 * q + 2];
-                    // staged per point: b_m = w dn_m and g_m = w (eta/h_T phi_m - dn_m): the pair's term is  phi_i g_j - b_i phi_j
+                    dd pbx[K1 + 1], pby[K1 + 1];
+                    pbx[0] = KIND == 0 ? dd_from(w) : two_prod(w, KIND == 1 ? nx : ny);
+                    pby[0] = dd_from(1.0);
 #pragma unroll
-                    for (int m = 0; m < RBS; ++m) {
-                        const dd bm = dd_mul_d(dd_add(dd_mul_d(gx[m], nx), dd_mul_d(gy[m], ny)), w);
-                        dd_store(S + oBPH + 2 * (l * RBS + m), phi[m]);
-                        dd_store(S + oBDN + 2 * (l * RBS + m), bm);
-                        dd_store(S + oBG + 2 * (l * RBS + m), dd_sub(dd_mul_d(dd_mul_d(phi[m], eta_h), w), bm));
+                    for (int e = 1; e <= K1; ++e) { pbx[e] = dd_mul_d(pbx[e - 1], bx); pby[e] = dd_mul_d(pby[e - 1], by); }
+                    if (first) {                                             // (the usual case is one point per lane: no addition at all)
+#pragma unroll
+                        for (int k = K0; k <= K1; ++k)
+#pragma unroll
+                            for (int r = 0; r <= k; ++r) acc[k * (k + 1) / 2 + r - B0] = dd_mul(pbx[k - r], pby[r]);
+                        first = false;
+                    } else {
+#pragma unroll
+                        for (int k = K0; k <= K1; ++k)
+#pragma unroll
+                            for (int r = 0; r <= k; ++r)
+                                acc[k * (k + 1) / 2 + r - B0] = dd_add_fast(acc[k * (k + 1) / 2 + r - B0], dd_mul(pbx[k - r], pby[r]));
                     }
                 }
-                wave_sync();
-                const int nq = (int)((i1 - base) < (uint32_t)CHB ? (i1 - base) : (uint32_t)CHB);
-                if (has_pair) {
-                    for (int t = 0; t < nq; ++t) {
-                        const dd fi = dd_load(S + oBPH + 2 * (t * RBS + pi_)), fj = dd_load(S + oBPH + 2 * (t * RBS + pj_));
-                        const dd bi = dd_load(S + oBDN + 2 * (t * RBS + pi_)), gj = dd_load(S + oBG + 2 * (t * RBS + pj_));
-                        nacc = dd_add_fast(nacc, dd_sub_fast(dd_mul(fi, gj), dd_mul(bi, fj)));
-                    }
+                if (first) {
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) acc[m] = dd_from(0.0);
                 }
-                wave_sync();
+                dd tot; bool ok = true;
+                const int m = lanes_transpose_reduce<NM, 32>(acc, l, dd_from(0.0), [](dd u, dd v_) { return dd_add_fast(u, v_); },
+                                                             [](dd u, int off) { return dd_shfl_xor(u, off); }, tot, ok);
+                if (ok) dd_store(dst + 2 * (B0 + m), tot);
+            };
+            {
+                using I0 = std::integral_constant<int, 0>;
+                constexpr int KS = DM >= 4 ? DM - 2 : 0;              // (k = 2: degrees 0..4 and 5..6 apart: 15 + 13 accumulators, not 28)
+                iface_moments(I0(), I0(), std::integral_constant<int, KS>(), S + oIM);
+                if constexpr (KS < DM) iface_moments(I0(), std::integral_constant<int, KS + 1>(), std::integral_constant<int, DM>(), S + oIM);
+                iface_moments(std::integral_constant<int, 1>(), I0(), std::integral_constant<int, DM - 1>(), S + oIX);
+                iface_moments(std::integral_constant<int, 2>(), I0(), std::integral_constant<int, DM - 1>(), S + oIY);
             }
-            if (has_pair) {
+            wave_sync();
+            if (l < RBS * (RBS + 1) / 2) {                                              // this lane's pair, i <= j
+                int pj_ = 0;
+                while ((pj_ + 1) * (pj_ + 2) / 2 <= l && pj_ + 1 < RBS) ++pj_;
+                const int pi_ = l - pj_ * (pj_ + 1) / 2;
+                int p1, r1, p2, r2;
+                mono_exps(pi_, p1, r1);
+                mono_exps(pj_, p2, r2);
+                const int P = p1 + p2, R = r1 + r2;
+                dd nacc = dd_mul_d(dd_load(S + oIM + 2 * mono_index(P, R)), eta_h);
+                dd g = dd_from(0.0);
+                if (P > 0) g = dd_mul_d(dd_load(S + oIX + 2 * mono_index(P - 1, R)), (double)P);
+                if (R > 0) g = dd_add(g, dd_mul_d(dd_load(S + oIY + 2 * mono_index(P, R - 1)), (double)R));
+                nacc = dd_sub(nacc, dd_mul_d(g, ih));
                 const dd v = dd_add(dd_load(S + oST + 2 * (pi_ + pj_ * LD)), nacc);
                 dd_store(S + oST + 2 * (pi_ + pj_ * LD), v);
                 dd_store(S + oST + 2 * (pj_ + pi_ * LD), v);
@@ -304,11 +379,16 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
         PA_CUT_TICK(3);
         // ---- C: gr_rhs (cuthho_square.cpp:362-383); face points of the `where` part
         {
-            if (l < NFPT) {
-                const int f = l / FACE_SLOTS, qq = l % FACE_SLOTS;
-                const bool ok = qq < a.fl_cnt[cc * 4 + f];
-                const double *src = a.fl_xyw + (((size_t)cc * 4 + f) * FACE_SLOTS + qq) * 3;
-                const double x = ok ? src[0] : barx, y = ok ? src[1] : bary, w = ok ? src[2] : 0.0;
+            const int pt_ = l / LPC, sub = l % LPC;
+            if (!PA_CUT_PREFETCH) {
+                c_src = a.fl_xyw + (((size_t)cc * 4 + c_pt / FACE_SLOTS) * FACE_SLOTS + c_pt % FACE_SLOTS) * 3;
+                c_x = c_src[0]; c_y = c_src[1]; c_w = c_src[2];
+                c_n = a.fl_cnt[cc * 4 + c_pt / FACE_SLOTS];
+            }
+            if (pt_ < NFPT) {
+                const int f = pt_ / FACE_SLOTS, qq = pt_ % FACE_SLOTS;
+                const bool ok = qq < c_n;
+                const double x = ok ? c_x : barx, y = ok ? c_y : bary, w = ok ? c_w : 0.0;
                 const int f1 = (f + 1) & 3;
                 const double ex = px[f1] - px[f], ey = py[f1] - py[f];
                 const double len = sqrt(ex * ex + ey * ey);
@@ -319,25 +399,36 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
                 const double fbx = 0.5 * (ax + bxx), fby = 0.5 * (ay + byy);
                 const double ep = 4.0 * ((fbx - ax) * (x - fbx) + (fby - ay) * (y - fby)) / (len * len);
                 const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
-                dd phi[RBS], gx[RBS], gy[RBS];
-                basis_dd(bx, by, phi, gx, gy);
+                dd pbx[RD + 1], pby[RD + 1];
+                powers_dd(bx, by, pbx, pby);
 #pragma unroll
-                for (int m = 0; m < RBS; ++m) {
-                    dd_store(S + oCPH + 2 * (l * RBS + m), phi[m]);
-                    dd_store(S + oCDN + 2 * (l * RBS + m), dd_mul_d(dd_add(dd_mul_d(gx[m], nx), dd_mul_d(gy[m], ny)), w));
+                for (int it = 0; it < (RBS + LPC - 1) / LPC; ++it) {
+                    const int m = sub + it * LPC;
+                    if (m < RBS) {
+                        dd phi, gx, gy;
+                        basis_dd_one(pbx, pby, m, phi, gx, gy);
+                        dd_store(S + oCPH + 2 * (pt_ * RBS + m), phi);
+                        dd_store(S + oCDN + 2 * (pt_ * RBS + m), dd_mul_d(dd_add(dd_mul_d(gx, nx), dd_mul_d(gy, ny)), w));
+                    }
                 }
-                dd pe = dd_from(1.0);
+                if (sub == LPC - 1) {
+                    dd pe = dd_from(1.0);
 #pragma unroll
-                for (int k = 0; k < FBS; ++k) { dd_store(S + oCFB + 2 * (l * FBS + k), pe); pe = dd_mul_d(pe, ep); }
+                    for (int k = 0; k < FBS; ++k) { dd_store(S + oCFB + 2 * (pt_ * FBS + k), pe); pe = dd_mul_d(pe, ep); }
+                }
             }
             wave_sync();
             for (int e = l; e < RBS * MS; e += 64) {
                 const int i = e % RBS, j = e / RBS;
                 dd sacc;
                 if (j < CBS) {
-                    sacc = dd_load(S + oST + 2 * (i + j * LD));
+                    // (four running sums over the face points: one sum is a chain of NFPT dependent additions)
+                    dd s4[4] = {dd_from(0.0), dd_from(0.0), dd_from(0.0), dd_from(0.0)};
+                    static_assert(NFPT % 4 == 0, "four running sums");
+#pragma unroll
                     for (int p_ = 0; p_ < NFPT; ++p_)
-                        sacc = dd_sub_fast(sacc, dd_mul(dd_load(S + oCDN + 2 * (p_ * RBS + i)), dd_load(S + oCPH + 2 * (p_ * RBS + j))));
+                        s4[p_ & 3] = dd_add_fast(s4[p_ & 3], dd_mul(dd_load(S + oCDN + 2 * (p_ * RBS + i)), dd_load(S + oCPH + 2 * (p_ * RBS + j))));
+                    sacc = dd_sub_fast(dd_load(S + oST + 2 * (i + j * LD)), dd_add_fast(dd_add_fast(s4[0], s4[1]), dd_add_fast(s4[2], s4[3])));
                 } else {
                     const int f = (j - CBS) / FBS, k = (j - CBS) % FBS;
                     sacc = dd_from(0.0);
@@ -349,64 +440,89 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
             wave_sync();
         }
         PA_CUT_TICK(4);
-        // ---- D: llt(gr_lhs) in place on the stiffness image (cuthho_square.cpp:385), lane i = row i; 1 / L_jj kept in the
-        // (dead) moment table
+        // ---- D: oper = llt(gr_lhs).solve(gr_rhs) (cuthho_square.cpp:385) in registers, one lane per COLUMN of [gr_lhs | gr_rhs]
+        // (rbs + msize lanes).  Right-looking: at pivot j every lane forms y = v_j / sqrt(d) -- a column of gr_lhs its entry L_kj (the
+        // matrix is kept whole and symmetric), a column of gr_rhs its forward-substituted entry -- and takes  v_i -= L_ij y  for the
+        // rows below, L_ij read from lane j's registers (v_readlane: no LDS image of the factor, no barrier per pivot).  A pivot's
+        // dependent path is rsqrt -> y -> ONE update of the next pivot column; the updates of a step are independent of each other.
+        // The left-looking form on an LDS image it replaces had the j-term sum in front of every pivot, and its substitutions kept
+        // msize lanes busy with a chain of rbs (rbs - 1) / 2 dependent subtractions each way: 51 k of the kernel's 230 k clocks.
         {
-            double *RS = S + oMOM;
-#pragma unroll 1
+            static_assert(RBS + MS <= 64, "a lane per column of [gr_lhs | gr_rhs]");
+            const bool isA = l < RBS, isG = l >= RBS && l < RBS + MS;
+            const int gc = isG ? l - RBS : 0;
+            dd v[RBS], rsv[RBS];
+#pragma unroll
+            for (int i = 0; i < RBS; ++i)
+                v[i] = isA ? dd_load(S + oST + 2 * (i + l * LD)) : isG ? dd_load(S + oGR + 2 * (i + gc * RBS)) : dd_from(1.0);
+#pragma unroll
             for (int j = 0; j < RBS; ++j) {
-                dd sj = dd_from(0.0);
-                if (l >= j && l < RBS) {
-                    sj = dd_load(S + oST + 2 * (l + j * LD));
-                    for (int k = 0; k < j; ++k)
-                        sj = dd_sub(sj, dd_mul(dd_load(S + oST + 2 * (l + k * LD)), dd_load(S + oST + 2 * (j + k * LD))));
-                    if (l == j) dd_store(S + oST + 2 * (j + j * LD), sj);                 // the pivot, unscaled, for the other rows
-                }
-                wave_sync();
-                const dd piv = dd_load(S + oST + 2 * (j + j * LD));
+                const dd piv = dd_readlane(v[j], j);
                 if (!(piv.hi > 0.0) && !bad) bad = j + 1;
-                const dd rs = dd_rsqrt(piv);
-                wave_sync();
-                if (l >= j && l < RBS) dd_store(S + oST + 2 * (l + j * LD), dd_mul(sj, rs));   // L_ij = s_i / sqrt(d); L_jj = sqrt(d)
-                if (l == 0) dd_store(RS + 2 * j, rs);
-                wave_sync();
+                const dd rs = dd_rsqrt_1(piv);
+                rsv[j] = rs;
+                const dd y = dd_mul(v[j], rs);
+#pragma unroll
+                for (int i = j + 1; i < RBS; ++i) {
+                    const dd scaled = dd_mul(v[i], rs);                  // (lane j: L_ij)
+                    const dd lij = dd_readlane(scaled, j);
+                    const dd upd = dd_sub_fast(v[i], dd_mul(lij, y));
+                    v[i].hi = l == j ? scaled.hi : l > j ? upd.hi : v[i].hi;
+                    v[i].lo = l == j ? scaled.lo : l > j ? upd.lo : v[i].lo;
+                }
+                v[j].hi = l >= j ? y.hi : v[j].hi;
+                v[j].lo = l >= j ? y.lo : v[j].lo;
             }
             PA_CUT_TICK(5);
-            // oper = L^-T L^-1 gr_rhs, column c = lane
-            if (l < MS) {
-                dd xv[RBS];
+            // backward substitution, column-oriented as well: x_i = v_i / L_ii, then v_k -= L_ik x_i for the rows above
 #pragma unroll
-                for (int k = 0; k < RBS; ++k) xv[k] = dd_load(S + oGR + 2 * (k + l * RBS));
+            for (int i = RBS - 1; i >= 0; --i) {
+                const dd x = dd_mul(v[i], rsv[i]);
+                if (isG) v[i] = x;
 #pragma unroll
-                for (int i = 0; i < RBS; ++i) {
-                    dd sv = xv[i];
-#pragma unroll
-                    for (int k = 0; k < i; ++k) sv = dd_sub_fast(sv, dd_mul(dd_load(S + oST + 2 * (i + k * LD)), xv[k]));
-                    xv[i] = dd_mul(sv, dd_load(RS + 2 * i));
+                for (int k = 0; k < i; ++k) {
+                    const dd lik = dd_readlane(v[i], k);                 // entry i of column k of L (lanes < rbs are not touched here)
+                    const dd upd = dd_sub_fast(v[k], dd_mul(lik, x));
+                    if (isG) v[k] = upd;
                 }
+            }
+            if (isG) {
 #pragma unroll
-                for (int i = RBS - 1; i >= 0; --i) {
-                    dd sv = xv[i];
-#pragma unroll
-                    for (int k = i + 1; k < RBS; ++k) sv = dd_sub_fast(sv, dd_mul(dd_load(S + oST + 2 * (k + i * LD)), xv[k]));
-                    xv[i] = dd_mul(sv, dd_load(RS + 2 * i));
-                }
-#pragma unroll
-                for (int k = 0; k < RBS; ++k) dd_store(S + oOP + 2 * (k + l * RBS), xv[k]);
+                for (int k = 0; k < RBS; ++k) dd_store(S + oOP + 2 * (k + gc * RBS), v[k]);
             }
             wave_sync();
             if (a.oper != nullptr)
                 for (int e = l; e < RBS * MS; e += 64) a.oper[(size_t)cc * (RBS * MS) + e] = dd_round(dd_load(S + oOP + 2 * e));
         }
         PA_CUT_TICK(6);
-        // ---- E: data = gr_rhs^T oper (cuthho_square.cpp:386), rounded once, kept in the LDS image
+        // (the face point of stage F and the interface point of stage H: their round trips run under stage E)
+        if (PA_CUT_PREFETCH) {
+            const int fp = imin(l, NFPT - 1);
+            const double *src = a.fs_xyw + (((size_t)cc * 4 + fp / FACE_SLOTS) * FACE_SLOTS + fp % FACE_SLOTS) * 3;
+            f_x = src[0]; f_y = src[1]; f_w = src[2];
+            f_n = a.fs_cnt[cc * 4 + fp / FACE_SLOTS];
+            if (a.rhs != nullptr) {
+                const uint32_t r0 = a.ir_off[cc], r1 = a.ir_off[cc + 1];
+                if (r0 + l < r1) { h_x = a.ir_xyw[3 * (r0 + l)]; h_y = a.ir_xyw[3 * (r0 + l) + 1]; h_w = a.ir_xyw[3 * (r0 + l) + 2]; }
+            }
+        }
+        // ---- E: data = gr_rhs^T oper (cuthho_square.cpp:386) = G^T A^-1 G, symmetric: the entries i <= j, two running sums each,
+        // rounded once, mirrored into the LDS image
 #pragma unroll 1
-        for (int e = l; e < MS * MS; e += 64) {
-            const int i = e % MS, j = e / MS;
-            dd sacc = dd_from(0.0);
+        for (int e = l; e < MS * (MS + 1) / 2; e += 64) {
+            int j = (int)((__fsqrt_rn((float)(8 * e + 1)) - 1.0f) * 0.5f);      // column of packed entry e: j (j + 1) / 2 <= e
+            j += (j + 1) * (j + 2) / 2 <= e ? 1 : 0;
+            j -= j * (j + 1) / 2 > e ? 1 : 0;
+            const int i = e - j * (j + 1) / 2;
+            dd s0 = dd_from(0.0), s1 = dd_from(0.0);
 #pragma unroll
-            for (int k = 0; k < RBS; ++k) sacc = dd_add_fast(sacc, dd_mul(dd_load(S + oGR + 2 * (k + i * RBS)), dd_load(S + oOP + 2 * (k + j * RBS))));
-            S[oDATA + e] = dd_round(sacc);
+            for (int k = 0; k < RBS; ++k) {
+                const dd t = dd_mul(dd_load(S + oGR + 2 * (k + i * RBS)), dd_load(S + oOP + 2 * (k + j * RBS)));
+                if (k & 1) s1 = dd_add_fast(s1, t); else s0 = dd_add_fast(s0, t);
+            }
+            const double r = dd_round(dd_add_fast(s0, s1));
+            S[oDATA + i + j * MS] = r;
+            S[oDATA + j + i * MS] = r;
         }
         wave_sync();
         } else {
@@ -538,9 +654,13 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
         {
             if (l < NFPT) {
                 const int f = l / FACE_SLOTS, qq = l % FACE_SLOTS;
-                const bool ok = qq < a.fs_cnt[cc * 4 + f];
-                const double *src = a.fs_xyw + (((size_t)cc * 4 + f) * FACE_SLOTS + qq) * 3;
-                const double x = ok ? src[0] : barx, y = ok ? src[1] : bary, w = ok ? src[2] : 0.0;
+                if (!DD || !PA_CUT_PREFETCH) {
+                    const double *src = a.fs_xyw + (((size_t)cc * 4 + f) * FACE_SLOTS + qq) * 3;
+                    f_x = src[0]; f_y = src[1]; f_w = src[2];
+                    f_n = a.fs_cnt[cc * 4 + f];
+                }
+                const bool ok = qq < f_n;
+                const double x = ok ? f_x : barx, y = ok ? f_y : bary, w = ok ? f_w : 0.0;
                 const int f1 = (f + 1) & 3;
                 const double ex = px[f1] - px[f], ey = py[f1] - py[f];
                 const double len2 = ex * ex + ey * ey;
@@ -574,32 +694,42 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
                 S[oTR + fk + i * NF] = s;
             }
             wave_sync();
-            if (l < CBS) {                                             // mass.llt().solve(trace), column l (:615)
-#pragma unroll 1
-                for (int f = 0; f < 4; ++f) {
-                    if (a.fs_cnt[cc * 4 + f] == 0) continue;
-                    double Lf[FBS][FBS], x[FBS];
-                    for (int j = 0; j < FBS; ++j) {                    // tiny Cholesky, redundantly per lane
+            static_assert(4 * CBS <= 64, "a lane per (face, column)");
+            if (l < 4 * CBS) {                                         // mass.llt().solve(trace) (:615): one lane per (face, column)
+                const int f = l / CBS, c = l % CBS;                    // (the four faces one after the other on cbs lanes: a chain of
+                if (a.fs_cnt[cc * 4 + f] != 0) {                       //  4 x 12 square roots and divisions)
+                    double Lf[FBS][FBS], ri[FBS], x[FBS];
+#pragma unroll
+                    for (int j = 0; j < FBS; ++j) {                    // tiny Cholesky, redundantly per lane; 1 / L_jj kept
                         double d = S[oMF + f * FBS * FBS + j + j * FBS];
+#pragma unroll
                         for (int k = 0; k < j; ++k) d -= Lf[j][k] * Lf[j][k];
-                        Lf[j][j] = sqrt(d);
+                        ri[j] = fast_rsqrt<2>(d);
+                        Lf[j][j] = d * ri[j];
+#pragma unroll
                         for (int i = j + 1; i < FBS; ++i) {
-                            double s = S[oMF + f * FBS * FBS + i + j * FBS];
-                            for (int k = 0; k < j; ++k) s -= Lf[i][k] * Lf[j][k];
-                            Lf[i][j] = s / Lf[j][j];
+                            double s_ = S[oMF + f * FBS * FBS + i + j * FBS];
+#pragma unroll
+                            for (int k = 0; k < j; ++k) s_ -= Lf[i][k] * Lf[j][k];
+                            Lf[i][j] = s_ * ri[j];
                         }
                     }
+#pragma unroll
                     for (int i = 0; i < FBS; ++i) {
-                        double s = S[oTR + (f * FBS + i) + l * NF];
-                        for (int k = 0; k < i; ++k) s -= Lf[i][k] * x[k];
-                        x[i] = s / Lf[i][i];
+                        double s_ = S[oTR + (f * FBS + i) + c * NF];
+#pragma unroll
+                        for (int k = 0; k < i; ++k) s_ -= Lf[i][k] * x[k];
+                        x[i] = s_ * ri[i];
                     }
+#pragma unroll
                     for (int i = FBS - 1; i >= 0; --i) {
-                        double s = x[i];
-                        for (int k = i + 1; k < FBS; ++k) s -= Lf[k][i] * x[k];
-                        x[i] = s / Lf[i][i];
+                        double s_ = x[i];
+#pragma unroll
+                        for (int k = i + 1; k < FBS; ++k) s_ -= Lf[k][i] * x[k];
+                        x[i] = s_ * ri[i];
                     }
-                    for (int i = 0; i < FBS; ++i) S[oPT + (f * FBS + i) + l * NF] = x[i];
+#pragma unroll
+                    for (int i = 0; i < FBS; ++i) S[oPT + (f * FBS + i) + c * NF] = x[i];
                 }
             }
             wave_sync();
@@ -625,16 +755,24 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
             }
             wave_sync();
             const size_t off = (size_t)cc * (MS * MS);
+            // (the stabilization is symmetric like data: the entries i <= jc, two running sums each, both copies stored)
 #pragma unroll 1
-            for (int e = l; e < MS * MS; e += 64) {
-                const int i = e % MS, jc = e / MS;
-                double s = 0.0;
+            for (int e = l; e < MS * (MS + 1) / 2; e += 64) {
+                int jc = (int)((__fsqrt_rn((float)(8 * e + 1)) - 1.0f) * 0.5f);
+                jc += (jc + 1) * (jc + 2) / 2 <= e ? 1 : 0;
+                jc -= jc * (jc + 1) / 2 > e ? 1 : 0;
+                const int i = e - jc * (jc + 1) / 2;
+                double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                for (int fk = 0; fk < NF; ++fk) s += OPF[fk + i * NF] * WF[fk + jc * NF];
-                const double st = s * (1.0 / hT), dt = S[oDATA + e];
-                if (a.lc != nullptr) a.lc[off + e] = dt + st;
-                if (a.data != nullptr) a.data[off + e] = dt;
-                if (a.stab != nullptr) a.stab[off + e] = st;
+                for (int fk = 0; fk < NF; fk += 2) {
+                    s0 += OPF[fk + i * NF] * WF[fk + jc * NF];
+                    s1 += OPF[fk + 1 + i * NF] * WF[fk + 1 + jc * NF];
+                }
+                const double st = (s0 + s1) * (1.0 / hT), dt = S[oDATA + i + jc * MS];
+                const int e1 = i + jc * MS, e2 = jc + i * MS;
+                if (a.lc != nullptr) { a.lc[off + e1] = dt + st; a.lc[off + e2] = dt + st; }
+                if (a.data != nullptr) { a.data[off + e1] = dt; a.data[off + e2] = dt; }
+                if (a.stab != nullptr) { a.stab[off + e1] = st; a.stab[off + e2] = st; }
             }
             if (a.info != nullptr && l == 0) a.info[cc] = bad;
         }
@@ -654,7 +792,9 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
                 constexpr int HROW = 2 * (RD + 1) + 3;
                 static_assert(HROW <= ROWW, "stage H rows fit the point table of stage A");
                 if (q < r1) {
-                    const double x = a.ir_xyw[3 * q], y = a.ir_xyw[3 * q + 1];
+                    const bool pre = DD && PA_CUT_PREFETCH && base == r0;   // (loaded under stage E)
+                    const double x = pre ? h_x : a.ir_xyw[3 * q], y = pre ? h_y : a.ir_xyw[3 * q + 1];
+                    const double wq = pre ? h_w : a.ir_xyw[3 * q + 2];
                     double nx, ny;
                     a.ls.normal(x, y, nx, ny);
                     const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
@@ -665,7 +805,7 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
                         S[oTPHI + HROW * l + (RD + 1) + e] = vy;
                         vx *= bx; vy *= by;
                     }
-                    S[oTPHI + HROW * l + 2 * (RD + 1)] = a.ir_xyw[3 * q + 2] * (a.bcs_fn == FN_SAMPLED ? a.bcs_vals[q] : builtin_fn(a.bcs_fn, x, y));
+                    S[oTPHI + HROW * l + 2 * (RD + 1)] = wq * (a.bcs_fn == FN_SAMPLED ? a.bcs_vals[q] : builtin_fn(a.bcs_fn, x, y));
                     S[oTPHI + HROW * l + 2 * (RD + 1) + 1] = nx;
                     S[oTPHI + HROW * l + 2 * (RD + 1) + 2] = ny;
                 }

@@ -7,17 +7,17 @@ mp.mp.dps = 60
 n = 1 << 16
 raw = np.fromfile("gpurun_out/dd_check.bin", dtype=np.float64)
 ah, al, bh, bl, d = (raw[i * n:(i + 1) * n] for i in range(5))
-out = raw[5 * n:].reshape(12, n)
-names = ["add", "mul", "mul_d", "rsqrt", "sub", "two_prod"]
-worst = [0.0] * 6
+out = raw[5 * n:].reshape(14, n)
+names = ["add", "mul", "mul_d", "rsqrt", "sub", "two_prod", "rsqrt_1"]
+worst = [0.0] * 7
 for i in range(0, n, 16):
     A, B = F(ah[i]) + F(al[i]), F(bh[i]) + F(bl[i])
-    for q in range(6):
+    for q in range(7):
         got = F(out[2 * q, i]) + F(out[2 * q + 1, i])
         if q == 0: want, scale = A + B, abs(A) + abs(B)
         elif q == 1: want = A * B; scale = abs(want)
         elif q == 2: want = A * F(d[i]); scale = abs(want)
-        elif q == 3:
+        elif q in (3, 6):
             X = F(abs(ah[i]) + 0.1) + F(al[i])
             w = 1 / mp.sqrt(mp.mpf(X.numerator) / mp.mpf(X.denominator))
             e = abs((mp.mpf(got.numerator) / mp.mpf(got.denominator) - w) / w)
