@@ -6,7 +6,7 @@ for W in quad1024_k2 quad1024_k2_general quad1024_k1 quad1024_k3 quad256_k1_fan 
   timeout -k 10 300 python bench.py --workload $W --mode L --steps 10 --warmup 3 2>/dev/null | tail -1 >> $OUT
   echo "$W L done"
 done
-for W in quad1024_k2 quad1024_k1 quad1024_k3 obstacle512_k1 quad2048_k3; do
+for W in quad1024_k2 quad1024_k2_general quad1024_k1 quad1024_k3 obstacle512_k1 cuthho512_k2 quad2048_k3; do
   timeout -k 10 300 python bench.py --workload $W --mode C --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT
   echo "$W C done"
 done
