@@ -310,10 +310,10 @@ class BatchAssembler:
         return out
 
     # ---- cutHHO fictitious domain (cuthho_square -f) ------------------------------------
-    def cut_preprocess(self, N, radius=0.35, center=(0.5, 0.5), refsteps=4, rows=None):
-        """cuthho_square.cpp:2026-2052: mesh, circle level set, default (-D) preprocessing.  rows = (row_begin, row_end): the
-        context keeps that slab of cell rows (pa_cut_preprocess_rows)."""
-        self.level_set = capi.LevelSet(0, radius, center[0], center[1], 0.0)
+    def cut_preprocess(self, N, radius=0.35, center=(0.5, 0.5), refsteps=4, rows=None, line_y=None):
+        """cuthho_square.cpp:2026-2052: mesh, circle level set (or, line_y given, line_level_set y - line_y, :91-124), default (-D)
+        preprocessing.  rows = (row_begin, row_end): the context keeps that slab of cell rows (pa_cut_preprocess_rows)."""
+        self.level_set = capi.LevelSet(0, radius, center[0], center[1], 0.0) if line_y is None else capi.LevelSet(1, 0.0, 0.0, 0.0, line_y)
         self.ctx.cut_preprocess(N, N, self.level_set, refsteps, rows=rows)
         self.ncut, self.cell_loc, self.cut_index = self.ctx.cut_query()
         return self.ncut

@@ -148,17 +148,16 @@ int main()
                 return 1.0 + pt.x() + 2.0 * pt.y() + ((inside && !at_end) ? 5.0 : 0.0);
             };
             auto assm = make_assembler(m, hdi);
-            auto fresh = make_assembler(m, hdi);
+            auto fresh = make_assembler(m, hdi), plain = make_assembler(m, hdi);      // (each of these two sees ONE functor only)
             std::vector<T> sol(assm.RHS.size(), T(0));
             T seen = 0;
             for (auto &cl : m.cells) (void)assm.take_local_data(m, cl, sol, g1);              // sweep 1 fills the cache with g1
             for (auto &cl : m.cells) {                                                         // sweep 2: g2
                 auto got = assm.take_local_data(m, cl, sol, g2);
                 auto want = fresh.take_local_data(m, cl, sol, g2);
-                auto with_g1 = fresh.take_local_data(m, cl, sol, g1);
+                auto with_g1 = plain.take_local_data(m, cl, sol, g1);
                 ok = ok && max_abs_diff(got, want) == 0;
                 seen = std::max(seen, max_abs_diff(want, with_g1));
-                (void)fresh.take_local_data(m, cl, sol, g2);                                   // leave `fresh` holding g2 ...
             }
             ok = ok && seen > 1.0;                                                             // the bump reached some cell
         }

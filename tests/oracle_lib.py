@@ -462,11 +462,12 @@ class ObstacleAssembler(Assembler):
 class CutMesh:
     """cuthho_poly_mesh + the preprocessing of cuthho_square.cpp:2036-2052 (oracle side)."""
 
-    def __init__(self, N, radius=0.35, center=(0.5, 0.5), refsteps=4, agglomeration=False):
+    def __init__(self, N, radius=0.35, center=(0.5, 0.5), refsteps=4, agglomeration=False, line_y=None):
         L = lib()
         self.L = L
         self.N = N
-        self.ls = CutLevelSet(0, radius, center[0], center[1], 0.0)
+        # circle_level_set (cuthho_square.cpp:56-89) or, line_y given, line_level_set y - line_y (:91-124)
+        self.ls = CutLevelSet(0, radius, center[0], center[1], 0.0) if line_y is None else CutLevelSet(1, 0.0, 0.0, 0.0, line_y)
         self.h = L.cut_mesh_create(N, N, 0.0, 1.0, 0.0, 1.0)
         st = (L.cut_mesh_preprocess_agglomeration if agglomeration else L.cut_mesh_preprocess)(self.h, C.byref(self.ls), refsteps)
         if st != 0:

@@ -495,3 +495,28 @@ def test_cut_workload_in_condensed_mode(asm, N, k):
     # the merge touches the cut cells only
     plain = asm.condensed_ops(cd, fd, capi.QUAD_FAN, capi.STAB_NAIVE, rhs=rhs)
     assert torch.equal(plain[~cut], rec[~cut]) and not torch.equal(plain[cut], rec[cut])
+
+
+@pytest.mark.parametrize("N,k,line_y", [(10, 1, 0.53), (12, 2, 0.47), (9, 0, 0.5)])
+def test_cut_operators_with_the_line_level_set(asm, oracle, N, k, line_y):
+    """line_level_set (cuthho_square.cpp:91-124: phi = y - cut_y, normal (0, 1)): a row of cells cut by a horizontal line -- tags,
+    quadrature lists and every cut cell's operators against the oracle's restatement and the binary128 evaluation, as for the circle.
+    (line_y = 0.5 on the 9 x 9 mesh passes through no node; on an even mesh it would run along a grid line and cut nothing.)"""
+    from proton_amd.batch import to_rowcol
+    ncut = asm.cut_preprocess(N, refsteps=3, line_y=line_y)
+    ref = oracle.CutMesh(N, refsteps=3, line_y=line_y)
+    assert np.array_equal(asm.cell_loc, ref.cell_loc)
+    cut_cells = np.nonzero(ref.cell_loc == oracle.CUT_ON_INTERFACE)[0]
+    assert ncut == len(cut_cells) == N                      # one row of cells
+    out = asm.cut_local_ops(k)
+    asm.synchronize()
+    assert int(out["info"].abs().max().cpu()) == 0
+    di = oracle.degrees(k + 1, k)
+    oper, data, stab, lc, rhs = (to_rowcol(out["oper"]), to_rowcol(out["data"]), to_rowcol(out["stab"]),
+                                 to_rowcol(out["lc"]), out["rhs"].cpu().numpy())
+    for i, c in enumerate(cut_cells):
+        st, o_stab = ref.cut_stabilization(int(c), di)
+        st, o_rhs = ref.rhs(int(c), di.cell_deg)
+        assert nerr(stab[i], o_stab) < TOL
+        assert np.abs(rhs[i] - o_rhs).max() < 1e-12 * max(1.0, np.abs(o_rhs).max())
+    judge_cut_cells(ref, oracle, di, cut_cells, lc, oper, data, label="line y=%g N=%d k=%d:" % (line_y, N, k))
