@@ -170,6 +170,29 @@
 // kernel forms the heads of the 64 cells it visits next itself -- one cell per lane, the thread-per-cell code of hho_pre.hpp -- into a
 // ring of 64 records of its own in global memory (45 KB at k = 2: written and read back by the same compute unit within ~0.2 ms), and
 // reads them from there as before (per instance: proton_amd/_build.py)
+// Wavefront priority by stage (s_setprio 0..3): a wavefront raises its issue priority as it moves through a pass -- head 0, cell
+// columns of gr_rhs (S3b) 1, substitutions and the face part (S4..S6) 2, product + output (S7/S8, and the elimination of the
+// condensed mode) 3 -- so that of the three wavefronts of a SIMD the one closest to its stores wins the issue slot: the stores of
+// a pass go out earlier and the wavefronts of a SIMD drift apart in phase instead of queueing for the same pipe in the same stage.
+// Measured (A/B of tagged builds, 5 rounds each in one call, kernels of 1024 x 1024 cells): k = 2 L 1.204 -> 1.143 ms, k = 1 L
+// 0.438 -> 0.424, k = 3 L 2.470 -> 2.380, k = 2 C (rhs + operators + fill) 2.21 -> 2.05; out 3 alone 1.175 / 0.429 / 2.399; out 3
+// + substitutions 1: 1.160 / 0.424 / 2.395; the reverse (head 3, out 0) 1.202 / 0.433 / 2.483 against 1.212 / 0.440 / 2.513.
+// PA_PRIO_OUT = -1: no s_setprio at all (the kernels of rounds 1-2).
+#ifndef PA_PRIO_OUT
+#define PA_PRIO_OUT 3
+#endif
+#ifndef PA_PRIO_HEAD
+#define PA_PRIO_HEAD 0
+#endif
+#ifndef PA_PRIO_S3B      /* from S3b (cell columns of gr_rhs) on; -1: as the head */
+#define PA_PRIO_S3B 1
+#endif
+#ifndef PA_PRIO_MID      /* from S4 (substitutions) on; -1: as the stage before */
+#define PA_PRIO_MID 2
+#endif
+#ifndef PA_PRIO_S6       /* from S6 (face part of U, Z complete) on; -1: as the stage before */
+#define PA_PRIO_S6 -1
+#endif
 #ifndef PA_SELF_PRE
 #define PA_SELF_PRE 0
 #endif
@@ -1328,6 +1351,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         // of every stage out of the cell loop and the kernel spills.
         int l = l0;
         asm volatile("" : "+v"(l));
+        if (PA_PRIO_OUT >= 0) __builtin_amdgcn_s_setprio(PA_PRIO_HEAD);
 #if PA_LANE_RANGE
         l &= G - 1;      // tell the compiler the range again: its index products fit 24 bits (v_mul_u32_u24 / v_mad_u32_u24 are full rate)
 #endif
@@ -1606,6 +1630,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
 
         PA_TICK(1);
         // ================= S3b: column c of gr_rhs  hho.hpp:64-85 =====================
+        if (PA_PRIO_OUT >= 0 && PA_PRIO_S3B >= 0) __builtin_amdgcn_s_setprio(PA_PRIO_S3B >= 0 ? PA_PRIO_S3B : 0);
         PA_MARK("S3b");
         const int c = l < MS ? l : 0;
         double col[NR];
@@ -1766,6 +1791,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
 
         // ================= S4/S5: L L^T = gr_lhs (in place in ST[1:,1:]) ; Y = L^-1 gr_rhs  hho.hpp:63,92
         PA_TICK(2);
+        if (PA_PRIO_OUT >= 0 && PA_PRIO_MID >= 0) __builtin_amdgcn_s_setprio(PA_PRIO_MID >= 0 ? PA_PRIO_MID : 0);
         PA_MARK("S4");
         double *LG = S + C::oLG;                 // without the pre-pass: stiff[1:,1:], symmetric: row-major == column-major
         double lreg[C::NLR];                     // DPPFWD: [packed L | 1 / diagonal], element e in lane e mod 16 of a row, register e / 16
@@ -1878,6 +1904,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
 
         PA_TICK(3);
         // ================= S6: column c of U ==========================================
+        if (PA_PRIO_OUT >= 0 && PA_PRIO_S6 >= 0) __builtin_amdgcn_s_setprio(PA_PRIO_S6 >= 0 ? PA_PRIO_S6 : 0);
         PA_MARK("S6");
         if (UNIT_U && !(a.ablate & 32u)) {
 #pragma unroll
@@ -1998,6 +2025,7 @@ __global__ __launch_bounds__(64, (MODE == MODE_SPLIT && C::WAVES > 3) ? 3 : C::W
         // lane feeds 16 FMAs (the vector form reads one LDS double per FMA).  All 64 lanes work on one
         // cell at a time; the CPW cells of the wavefront are processed in turn.
         PA_TICK(5);
+        if (PA_PRIO_OUT >= 0) __builtin_amdgcn_s_setprio(PA_PRIO_OUT >= 0 ? PA_PRIO_OUT : 0);
         if (!SPLIT && !PA_LC_VALU) {
             PA_MARK("S7m");
             constexpr int NTL = (MS + 15) / 16;              // column tiles
