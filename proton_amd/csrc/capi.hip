@@ -132,6 +132,9 @@ struct pa_context {
     // interface_assembler tables (cuthho_square.cpp:1137-1185)
     int32_t *d_if_cell_table = nullptr, *d_if_face_table = nullptr;
     size_t if_num_all_cells = 0, if_num_other_faces = 0;
+    // scratch of pa_cut_interface_ops_batch ([data | stab- | stab+] of the cut cells), kept between calls
+    double *d_if_scratch = nullptr;
+    size_t if_scratch_cap = 0;                // doubles
     // records of the per-cell pre-pass (hho_pre.hpp), grown on demand, reused by every local-operator call
     double *d_pre = nullptr;
     size_t pre_capacity = 0;                  // doubles
@@ -195,6 +198,8 @@ static void release_cut(pa_context *ctx)
     if (ctx->d_cut_index) (void)hipFree(ctx->d_cut_index);
     if (ctx->d_if_cell_table) (void)hipFree(ctx->d_if_cell_table);
     if (ctx->d_if_face_table) (void)hipFree(ctx->d_if_face_table);
+    if (ctx->d_if_scratch) (void)hipFree(ctx->d_if_scratch);
+    ctx->d_if_scratch = nullptr; ctx->if_scratch_cap = 0;
     ctx->d_cut_cells = nullptr; ctx->d_cell_loc = nullptr; ctx->d_face_loc = nullptr; ctx->d_cut_index = nullptr;
     ctx->d_if_cell_table = ctx->d_if_face_table = nullptr;
     ctx->if_num_all_cells = ctx->if_num_other_faces = 0;
@@ -1861,19 +1866,24 @@ int pa_cut_interface_ops_batch(pa_context *ctx, int face_deg, const pa_level_set
         if (st != PA_OK) return st;
     }
     const int cbs = pa::P2(face_deg + 1), nfd = 4 * (face_deg + 1), ms = cbs + nfd, m2 = 2 * ms;
-    double *scratch = nullptr;                              // [data | stab_n | stab_p] when lc is requested
-    double *data = d_data, *stab_n = nullptr, *stab_p = nullptr;
+    double *data = d_data, *stab_n = nullptr, *stab_p = nullptr;      // [data | stab_n | stab_p] when lc is requested
     if (d_lc) {
+        // (the scratch lives in the context: a hipMalloc / hipFree pair and a stream synchronisation per call cost more than the
+        // kernels of a 512 x 512 mesh's cut cells; everything that touches it is ordered on the context's stream)
         const size_t need = (d_data ? 0 : ncut * (size_t)m2 * m2) + 2 * ncut * (size_t)ms * ms;
-        PA_HIP(ctx, hipMalloc((void **)&scratch, need * sizeof(double)));
-        double *p = scratch;
+        if (ctx->if_scratch_cap < need) {
+            if (ctx->d_if_scratch) { PA_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_if_scratch); ctx->d_if_scratch = nullptr; ctx->if_scratch_cap = 0; }
+            PA_HIP(ctx, hipMalloc((void **)&ctx->d_if_scratch, need * sizeof(double)));
+            ctx->if_scratch_cap = need;
+        }
+        double *p = ctx->d_if_scratch;
         if (!d_data) { data = p; p += ncut * (size_t)m2 * m2; }
         stab_n = p; stab_p = p + ncut * (size_t)ms * ms;
-        // make_hho_cut_stabilization of both sides through the fictitious-domain kernel
+        // make_hho_cut_stabilization of both sides through the fictitious-domain kernel (stabilization only: its stages A-E are skipped)
         st = pa_cut_local_ops_batch(ctx, face_deg, ls, PA_LOC_NEGATIVE, PA_FN_ONE, PA_FN_ONE, nullptr, nullptr, stab_n, nullptr, nullptr, nullptr);
         if (st == PA_OK)
             st = pa_cut_local_ops_batch(ctx, face_deg, ls, PA_LOC_POSITIVE, PA_FN_ONE, PA_FN_ONE, nullptr, nullptr, stab_p, nullptr, nullptr, nullptr);
-        if (st != PA_OK) { (void)hipFree(scratch); return st; }
+        if (st != PA_OK) return st;
     }
     pa::CutInterfaceArgs a;
     a.points = ctx->d_points; a.ptids = ctx->d_ptids; a.cut_cells = ctx->d_cut_cells; a.ncut = (uint32_t)ncut;
@@ -1885,7 +1895,8 @@ int pa_cut_interface_ops_batch(pa_context *ctx, int face_deg, const pa_level_set
     a.ls = pa::LevelSet{ls->kind, ls->radius, ls->alpha, ls->beta, ls->cut_y};
     a.rhs_fn = rhs_fn; a.kappa[0] = parms->kappa_1; a.kappa[1] = parms->kappa_2; a.eta = parms->eta;
     a.oper = d_oper; a.data = data; a.rhs = d_rhs; a.info = d_info;
-    const int grid = (int)(ncut < (size_t)ctx->num_cus * 2 ? ncut : (size_t)ctx->num_cus * 2);
+    // (46 KB of LDS per block at k = 2: three blocks per compute unit are resident)
+    const int grid = (int)(ncut < (size_t)ctx->num_cus * 3 ? ncut : (size_t)ctx->num_cus * 3);
     switch (face_deg) {
     case 0: hipLaunchKernelGGL((pa::cut_interface_kernel<0>), dim3(grid), dim3(64), 0, ctx->stream, a); break;
     case 1: hipLaunchKernelGGL((pa::cut_interface_kernel<1>), dim3(grid), dim3(64), 0, ctx->stream, a); break;
@@ -1896,11 +1907,6 @@ int pa_cut_interface_ops_batch(pa_context *ctx, int face_deg, const pa_level_set
         hipLaunchKernelGGL(pa::cut_interface_lc_kernel, dim3(grid), dim3(256), 0, ctx->stream, (uint32_t)ncut, cbs, nfd,
                            parms->kappa_1, parms->kappa_2, data, stab_n, stab_p, d_lc);
         e = hipGetLastError();
-    }
-    if (scratch) {
-        const hipError_t e2 = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(scratch);
-        if (e == hipSuccess) e = e2;
     }
     if (e != hipSuccess) { ctx->last_error = std::string("pa_cut_interface_ops_batch: ") + hipGetErrorString(e); return PA_ERR_HIP; }
     return PA_OK;

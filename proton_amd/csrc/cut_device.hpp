@@ -177,6 +177,10 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
         // loads of stages F and H issued early by the double-double path (see stage E)
         double f_x = 0.0, f_y = 0.0, f_w = 0.0, h_x = 0.0, h_y = 0.0, h_w = 0.0;
         int f_n = 0;
+        // Only the stabilization wanted (the interface problem takes make_hho_cut_stabilization of both sides from this kernel,
+        // cuthho_square.cpp:1694-1705): stages A-E -- the whole reconstruction -- are skipped.
+        const bool only_stab = a.oper == nullptr && a.data == nullptr && a.lc == nullptr && a.rhs == nullptr;
+        if (!only_stab) {
         if constexpr (DD) {
         // =========== stages A-E in double-double (see the head of the file) ===========
         static_assert(RBS * (RBS + 1) / 2 <= 64 && MS <= 64 && NFPT <= 64, "one lane per pair / column / point");
@@ -649,12 +653,13 @@ __global__ __launch_bounds__(64, DD ? 2 : 4) void cut_local_ops_kernel(CutArgs a
             wave_sync();
 
         }
+        }   // !only_stab
         PA_CUT_TICK(7);
         // ---- F: cut stabilization (cuthho_square.cpp:566-621): faces without points are skipped
         {
             if (l < NFPT) {
                 const int f = l / FACE_SLOTS, qq = l % FACE_SLOTS;
-                if (!DD || !PA_CUT_PREFETCH) {
+                if (!DD || !PA_CUT_PREFETCH || only_stab) {
                     const double *src = a.fs_xyw + (((size_t)cc * 4 + f) * FACE_SLOTS + qq) * 3;
                     f_x = src[0]; f_y = src[1]; f_w = src[2];
                     f_n = a.fs_cnt[cc * 4 + f];
