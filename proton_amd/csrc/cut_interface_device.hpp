@@ -138,22 +138,18 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
                             for (int r = 0; r <= k; ++r) racc[k * (k + 1) / 2 + r] += fv * (pbx[k - r].hi * pby[r].hi);
                     }
                 }
-#pragma unroll
-                for (int m = 0; m < NMOM; ++m) {
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) {
-                        const dd o = dd{__shfl_xor(macc[m].hi, off), __shfl_xor(macc[m].lo, off)};
-                        macc[m] = dd_add_fast(macc[m], o);
-                    }
-                    if (l == m) dd_store(S + oMOM + 2 * m, macc[m]);
+                // (the transposed butterfly of dd_arith.hpp: 29 exchanges for the 28 moments instead of 168)
+                {
+                    dd tot; bool ok = true;
+                    const int m = lanes_transpose_reduce<NMOM, 32>(macc, l, dd_from(0.0), [](dd u, dd v_) { return dd_add_fast(u, v_); },
+                                                                   [](dd u, int off) { return dd_shfl_xor(u, off); }, tot, ok);
+                    if (ok) dd_store(S + oMOM + 2 * m, tot);
                 }
                 if (a.rhs != nullptr) {
-#pragma unroll
-                    for (int m = 0; m < CBS; ++m) {
-#pragma unroll
-                        for (int off = 32; off >= 1; off >>= 1) racc[m] += __shfl_xor(racc[m], off);
-                        if (l == m) a.rhs[(size_t)cc * (2 * CBS) + side * CBS + m] = racc[m];      // :1710-1711
-                    }
+                    double tot; bool ok = true;
+                    const int m = lanes_transpose_reduce<CBS, 32>(racc, l, 0.0, [](double u, double v_) { return u + v_; },
+                                                                  [](double u, int off) { return __shfl_xor(u, off); }, tot, ok);
+                    if (ok) a.rhs[(size_t)cc * (2 * CBS) + side * CBS + m] = tot;      // :1710-1711 (the lanes that end with one entry hold the same sum)
                 }
             }
             wave_sync();
@@ -185,62 +181,104 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
                     gy[m] = r_ == 0 ? dd_from(0.0) : dd_mul(dd_mul(pbx[p_], pby[r_ > 0 ? r_ - 1 : 0]), two_prod((double)r_, ih));
                 }
         };
-        // ---- B: interface terms (:437-459): A_ij = sum k1 w phi_i (dphi_j.n), C_ij = sum k1 w eta/hT phi_i phi_j, entry per lane;
+        // ---- B: interface terms (:437-459): A_ij = sum k1 w phi_i (dphi_j.n), C_ij = sum k1 w eta/hT phi_i phi_j;
         //   (-,-) += C - A - A^T ;  (+,-) += A - C ;  (-,+) += A^T - C ;  (+,+) += C
+        // Through the moments of the interface measures w, w n_x, w n_y as in cut_device.hpp (stage B there): with P = p_i + p_j,
+        // R = r_i + r_j:  C_ij = k1 eta/hT M(P, R),  A_ij = k1 ih (p_j Mx(P - 1, R) + r_j My(P, R - 1)).
         {
             const uint32_t i0 = a.il_off[cc], i1 = a.il_off[cc + 1];
-            constexpr int NU = (RBS * RBS + 63) / 64;
-            dd accA[NU], accC[NU];
-#pragma unroll
-            for (int u = 0; u < NU; ++u) accA[u] = accC[u] = dd_from(0.0);
-            for (uint32_t base = i0; base < i1; base += CHB) {
-                const uint32_t q = base + l;
-                if (l < CHB && q < i1) {
-                    const double x = a.il_xyw[3 * q], y = a.il_xyw[3 * q + 1];
+            constexpr int DM = 2 * RD, NM1 = P2(DM - 1);
+            constexpr int oIM = oTPHI, oIX = oIM + 2 * NMOM, oIY = oIX + 2 * NM1;
+            static_assert(2 * (NMOM + 2 * NM1) <= CH * ROWW, "the interface moments fit the point table");
+            const bool in0 = i0 + l < i1;
+            const double x0 = in0 ? a.il_xyw[3 * (i0 + l)] : barx, y0 = in0 ? a.il_xyw[3 * (i0 + l) + 1] : bary;
+            const double w0 = in0 ? a.il_xyw[3 * (i0 + l) + 2] : 0.0;
+            double nx0, ny0;
+            a.ls.normal(x0, y0, nx0, ny0);
+            auto iface_moments = [&](auto kind_c, auto k0_c, auto k1_c, double *dst) {
+                constexpr int KIND = decltype(kind_c)::value, K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value;
+                constexpr int B0 = K0 * (K0 + 1) / 2, NM = P2(K1) - B0;
+                dd acc[NM];
+                bool first = true;
+                for (uint32_t q0 = i0; q0 < i1; q0 += 64) {
+                    const uint32_t q = q0 + l;
+                    const bool in = q < i1;
+                    double x = x0, y = y0, w = w0, nx = nx0, ny = ny0;
+                    if (q0 != i0) {
+                        x = in ? a.il_xyw[3 * q] : barx; y = in ? a.il_xyw[3 * q + 1] : bary; w = in ? a.il_xyw[3 * q + 2] : 0.0;
+                        if (KIND != 0) a.ls.normal(x, y, nx, ny);
+                    }
                     const double bx = (x - barx) * ihalf, by = (y - bary) * ihalf;
-                    double nx, ny;
-                    a.ls.normal(x, y, nx, ny);
-                    dd phi[RBS], gx[RBS], gy[RBS];
-                    basis_dd(bx, by, phi, gx, gy);
-                    const dd kw = two_prod(a.kappa[0], a.il_xyw[3 * q + 2]);
+                    dd pbx[K1 + 1], pby[K1 + 1];
+                    pbx[0] = KIND == 0 ? dd_from(w) : two_prod(w, KIND == 1 ? nx : ny);
+                    pby[0] = dd_from(1.0);
 #pragma unroll
-                    for (int m = 0; m < RBS; ++m) {
-                        dd_store(S + oBPH + 2 * (l * RBS + m), phi[m]);
-                        dd_store(S + oBDN + 2 * (l * RBS + m), dd_mul(dd_add(dd_mul_d(gx[m], nx), dd_mul_d(gy[m], ny)), kw));   // k1 w dn
-                    }
-                    dd_store(S + oTW + 2 * l, dd_mul_d(kw, eta_h));                                                             // k1 w eta/hT
-                }
-                wave_sync();
-                const int nq = (int)((i1 - base) < (uint32_t)CHB ? (i1 - base) : (uint32_t)CHB);
+                    for (int e = 1; e <= K1; ++e) { pbx[e] = dd_mul_d(pbx[e - 1], bx); pby[e] = dd_mul_d(pby[e - 1], by); }
+                    if (first) {
 #pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const int e = l + 64 * u;
-                    if (e < RBS * RBS) {
-                        const int i = e % RBS, j = e / RBS;
-                        for (int t = 0; t < nq; ++t) {
-                            const dd fi = dd_load(S + oBPH + 2 * (t * RBS + i)), fj = dd_load(S + oBPH + 2 * (t * RBS + j));
-                            accA[u] = dd_add_fast(accA[u], dd_mul(fi, dd_load(S + oBDN + 2 * (t * RBS + j))));
-                            accC[u] = dd_add_fast(accC[u], dd_mul(dd_mul(fi, fj), dd_load(S + oTW + 2 * t)));
-                        }
+                        for (int k = K0; k <= K1; ++k)
+#pragma unroll
+                            for (int r = 0; r <= k; ++r) acc[k * (k + 1) / 2 + r - B0] = dd_mul(pbx[k - r], pby[r]);
+                        first = false;
+                    } else {
+#pragma unroll
+                        for (int k = K0; k <= K1; ++k)
+#pragma unroll
+                            for (int r = 0; r <= k; ++r)
+                                acc[k * (k + 1) / 2 + r - B0] = dd_add_fast(acc[k * (k + 1) / 2 + r - B0], dd_mul(pbx[k - r], pby[r]));
                     }
                 }
-                wave_sync();
-            }
+                if (first) {
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int e = l + 64 * u;
-                if (e < RBS * RBS) { dd_store(S + oBA + 2 * e, accA[u]); dd_store(S + oBC + 2 * e, accC[u]); }
+                    for (int m = 0; m < NM; ++m) acc[m] = dd_from(0.0);
+                }
+                dd tot; bool ok = true;
+                const int m = lanes_transpose_reduce<NM, 32>(acc, l, dd_from(0.0), [](dd u, dd v_) { return dd_add_fast(u, v_); },
+                                                             [](dd u, int off) { return dd_shfl_xor(u, off); }, tot, ok);
+                if (ok) dd_store(dst + 2 * (B0 + m), tot);
+            };
+            {
+                using I0 = std::integral_constant<int, 0>;
+                constexpr int KS = DM >= 4 ? DM - 2 : 0;
+                iface_moments(I0(), I0(), std::integral_constant<int, KS>(), S + oIM);
+                if constexpr (KS < DM) iface_moments(I0(), std::integral_constant<int, KS + 1>(), std::integral_constant<int, DM>(), S + oIM);
+                iface_moments(std::integral_constant<int, 1>(), I0(), std::integral_constant<int, DM - 1>(), S + oIX);
+                iface_moments(std::integral_constant<int, 2>(), I0(), std::integral_constant<int, DM - 1>(), S + oIY);
             }
             wave_sync();
-            for (int e = l; e < RBS * RBS; e += 64) {
-                const int i = e % RBS, j = e / RBS;
-                const dd A_ = dd_load(S + oBA + 2 * (i + j * RBS)), At = dd_load(S + oBA + 2 * (j + i * RBS)), C_ = dd_load(S + oBC + 2 * (i + j * RBS));
-                double *p00 = S + oST + 2 * (i + j * LD2), *p10 = S + oST + 2 * ((RBS + i) + j * LD2);
-                double *p01 = S + oST + 2 * (i + (RBS + j) * LD2), *p11 = S + oST + 2 * ((RBS + i) + (RBS + j) * LD2);
-                dd_store(p00, dd_add(dd_load(p00), dd_sub(dd_sub(C_, A_), At)));
-                dd_store(p10, dd_add(dd_load(p10), dd_sub(A_, C_)));
-                dd_store(p01, dd_add(dd_load(p01), dd_sub(At, C_)));
-                dd_store(p11, dd_add(dd_load(p11), C_));
+            const dd k1e = two_prod(a.kappa[0], eta_h), k1i = two_prod(a.kappa[0], ih);
+            dd vA[(RBS * RBS + 63) / 64], vAt[(RBS * RBS + 63) / 64], vC[(RBS * RBS + 63) / 64];
+#pragma unroll
+            for (int u = 0; u < (RBS * RBS + 63) / 64; ++u) {
+                const int e = l + 64 * u;
+                vA[u] = vAt[u] = vC[u] = dd_from(0.0);
+                if (e < RBS * RBS) {
+                    const int i = e % RBS, j = e / RBS;
+                    int p1, r1, p2, r2;
+                    mono_exps(i, p1, r1);
+                    mono_exps(j, p2, r2);
+                    const int P = p1 + p2, R = r1 + r2;
+                    const dd mx = P > 0 ? dd_load(S + oIX + 2 * mono_index(P > 0 ? P - 1 : 0, R)) : dd_from(0.0);
+                    const dd my = R > 0 ? dd_load(S + oIY + 2 * mono_index(P, R > 0 ? R - 1 : 0)) : dd_from(0.0);
+                    vC[u] = dd_mul(dd_load(S + oIM + 2 * mono_index(P, R)), k1e);
+                    vA[u] = dd_mul(dd_add(dd_mul_d(mx, (double)p2), dd_mul_d(my, (double)r2)), k1i);
+                    vAt[u] = dd_mul(dd_add(dd_mul_d(mx, (double)p1), dd_mul_d(my, (double)r1)), k1i);
+                }
+            }
+            wave_sync();                                   // (the moment tables are dead: the point table is free again)
+#pragma unroll
+            for (int u = 0; u < (RBS * RBS + 63) / 64; ++u) {
+                const int e = l + 64 * u;
+                if (e < RBS * RBS) {
+                    const int i = e % RBS, j = e / RBS;
+                    const dd A_ = vA[u], At = vAt[u], C_ = vC[u];
+                    double *p00 = S + oST + 2 * (i + j * LD2), *p10 = S + oST + 2 * ((RBS + i) + j * LD2);
+                    double *p01 = S + oST + 2 * (i + (RBS + j) * LD2), *p11 = S + oST + 2 * ((RBS + i) + (RBS + j) * LD2);
+                    dd_store(p00, dd_add(dd_load(p00), dd_sub(dd_sub(C_, A_), At)));
+                    dd_store(p10, dd_add(dd_load(p10), dd_sub(A_, C_)));
+                    dd_store(p01, dd_add(dd_load(p01), dd_sub(At, C_)));
+                    dd_store(p11, dd_add(dd_load(p11), C_));
+                }
             }
             wave_sync();
         }
@@ -298,65 +336,75 @@ __global__ __launch_bounds__(64, 2) void cut_interface_kernel(CutInterfaceArgs a
             }
             wave_sync();
         }
-        // ---- D: the first unknown pinned (see the header comment): Cholesky of ST[1:, 1:] in place, lane i = row i (of the pinned
-        // system); 1 / L_jj in the (dead) moment table -- 2 NR <= 2 NMOM doubles
+        // ---- D: the first unknown pinned (see the header comment): Cholesky of ST[1:, 1:] and both substitutions in REGISTERS, one lane
+        // per column of [ST[1:, 1:] | gr_rhs[1:, :]] (NR + M2 lanes: 63 of the 64 at k = 2), right-looking as in cut_device.hpp: at
+        // pivot j every lane forms y = v_j / sqrt(d), then v_i -= L_ij y for the rows below with L_ij read from lane j (v_readlane);
+        // the backward substitution column-oriented the same way.  (The left-looking factorization on the LDS image and the
+        // substitutions of NR (NR - 1) / 2 = 171 dependent steps each way on M2 lanes were most of this kernel's time.)
         {
-            static_assert(NR <= NMOM, "the reciprocal pivots fit the moment table");
-            double *RS = S + oMOM;
-            auto LP = [&](int i, int j) -> double * { return S + oST + 2 * ((i + 1) + (j + 1) * LD2); };
-#pragma unroll 1
+            static_assert(NR + M2 <= 64, "a lane per column of the pinned system and of gr_rhs");
+            const bool isA = l < NR, isG = l >= NR && l < NR + M2;
+            const int gc = isG ? l - NR : 0;
+            dd v[NR], rsv[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+                v[i] = isA ? dd_load(S + oST + 2 * ((i + 1) + (l + 1) * LD2)) : isG ? dd_load(S + oGR + 2 * ((i + 1) + gc * N2)) : dd_from(1.0);
+#pragma unroll
             for (int j = 0; j < NR; ++j) {
-                dd sj = dd_from(0.0);
-                if (l >= j && l < NR) {
-                    sj = dd_load(LP(l, j));
-                    for (int k = 0; k < j; ++k) sj = dd_sub(sj, dd_mul(dd_load(LP(l, k)), dd_load(LP(j, k))));
-                    if (l == j) dd_store(LP(j, j), sj);
-                }
-                wave_sync();
-                const dd piv = dd_load(LP(j, j));
+                const dd piv = dd_readlane(v[j], j);
                 if (!(piv.hi > 0.0) && !bad) bad = j + 1;
-                const dd rs = dd_rsqrt(piv);
-                wave_sync();
-                if (l >= j && l < NR) dd_store(LP(l, j), dd_mul(sj, rs));
-                if (l == 0) dd_store(RS + 2 * j, rs);
-                wave_sync();
+                const dd rs = dd_rsqrt_1(piv);
+                rsv[j] = rs;
+                const dd y = dd_mul(v[j], rs);
+#pragma unroll
+                for (int i = j + 1; i < NR; ++i) {
+                    const dd scaled = dd_mul(v[i], rs);                  // (lane j: L_ij)
+                    const dd lij = dd_readlane(scaled, j);
+                    const dd upd = dd_sub_fast(v[i], dd_mul(lij, y));
+                    v[i].hi = l == j ? scaled.hi : l > j ? upd.hi : v[i].hi;
+                    v[i].lo = l == j ? scaled.lo : l > j ? upd.lo : v[i].lo;
+                }
+                v[j].hi = l >= j ? y.hi : v[j].hi;
+                v[j].lo = l >= j ? y.lo : v[j].lo;
             }
-            if (l < M2) {
-                dd xv[NR];
 #pragma unroll
-                for (int k = 0; k < NR; ++k) xv[k] = dd_load(S + oGR + 2 * ((k + 1) + l * N2));
+            for (int i = NR - 1; i >= 0; --i) {
+                const dd x = dd_mul(v[i], rsv[i]);
+                if (isG) v[i] = x;
 #pragma unroll
-                for (int i = 0; i < NR; ++i) {
-                    dd sv = xv[i];
-#pragma unroll
-                    for (int k = 0; k < i; ++k) sv = dd_sub_fast(sv, dd_mul(dd_load(LP(i, k)), xv[k]));
-                    xv[i] = dd_mul(sv, dd_load(RS + 2 * i));
+                for (int k = 0; k < i; ++k) {
+                    const dd lik = dd_readlane(v[i], k);                 // entry i of column k of L (lanes < NR are not touched here)
+                    const dd upd = dd_sub_fast(v[k], dd_mul(lik, x));
+                    if (isG) v[k] = upd;
                 }
+            }
+            if (isG) {
+                dd_store(S + oOP + 2 * (gc * N2), dd_from(0.0));          // the pinned unknown
 #pragma unroll
-                for (int i = NR - 1; i >= 0; --i) {
-                    dd sv = xv[i];
-#pragma unroll
-                    for (int k = i + 1; k < NR; ++k) sv = dd_sub_fast(sv, dd_mul(dd_load(LP(k, i)), xv[k]));
-                    xv[i] = dd_mul(sv, dd_load(RS + 2 * i));
-                }
-                dd_store(S + oOP + 2 * (l * N2), dd_from(0.0));
-#pragma unroll
-                for (int k = 0; k < NR; ++k) dd_store(S + oOP + 2 * ((k + 1) + l * N2), xv[k]);
+                for (int k = 0; k < NR; ++k) dd_store(S + oOP + 2 * ((k + 1) + gc * N2), v[k]);
             }
             wave_sync();
             if (a.oper != nullptr)
                 for (int e = l; e < N2 * M2; e += 64) a.oper[(size_t)cc * (N2 * M2) + e] = dd_round(dd_load(S + oOP + 2 * e));
         }
-        // ---- E: data = gr_rhs^T oper (:499), rounded once
+        // ---- E: data = gr_rhs^T oper (:499), symmetric: the entries i <= j, two running sums each, rounded once, both copies stored
         if (a.data != nullptr) {
             const size_t off = (size_t)cc * (M2 * M2);
 #pragma unroll 1
-            for (int e = l; e < M2 * M2; e += 64) {
-                const int i = e % M2, j = e / M2;
-                dd sacc = dd_from(0.0);
+            for (int e = l; e < M2 * (M2 + 1) / 2; e += 64) {
+                int j = (int)((__fsqrt_rn((float)(8 * e + 1)) - 1.0f) * 0.5f);
+                j += (j + 1) * (j + 2) / 2 <= e ? 1 : 0;
+                j -= j * (j + 1) / 2 > e ? 1 : 0;
+                const int i = e - j * (j + 1) / 2;
+                dd s0 = dd_from(0.0), s1 = dd_from(0.0);
 #pragma unroll 4
-                for (int k = 0; k < N2; ++k) sacc = dd_add_fast(sacc, dd_mul(dd_load(S + oGR + 2 * (k + i * N2)), dd_load(S + oOP + 2 * (k + j * N2))));
-                a.data[off + e] = dd_round(sacc);
+                for (int k = 0; k < N2; k += 2) {
+                    s0 = dd_add_fast(s0, dd_mul(dd_load(S + oGR + 2 * (k + i * N2)), dd_load(S + oOP + 2 * (k + j * N2))));
+                    s1 = dd_add_fast(s1, dd_mul(dd_load(S + oGR + 2 * (k + 1 + i * N2)), dd_load(S + oOP + 2 * (k + 1 + j * N2))));
+                }
+                const double r = dd_round(dd_add_fast(s0, s1));
+                a.data[off + i + (size_t)j * M2] = r;
+                a.data[off + j + (size_t)i * M2] = r;
             }
         }
         } else {
