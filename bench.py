@@ -55,6 +55,10 @@ WORKLOADS = {
     "cuthho512_k2": dict(N=512, cd=3, fd=2, quad="fan", stab="naive", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0, cut=True,
                          note="configs[2]: cuthho_square -M 512 -N 512 -k 2 -f, circle r=0.35, -r 4, node displacement: "
                               "uncut cells (fan quadrature, naive stabilization) + cut cells (Nitsche operators), merged"),
+    "cuthho512_k2_interface": dict(N=512, cd=3, fd=2, quad="fan", stab="naive", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0, cut=True,
+                                   interface=(1.0, 1.0, 5.0),
+                                   note="cuthho_square -M 512 -N 512 -k 2 -i (run_cuthho_interface, cuthho_square.cpp:1625-1846), kappa_1 = kappa_2 = 1, "
+                                        "eta = 5: every cell's one-sided operators + the cut cells' two-sided operators (2 msize unknowns each); mode L"),
     "quad1024_k2_general": dict(N=1024, cd=3, fd=2, quad="tensor", stab="fancy", lo=(0.0, 0.0), hi=(1.0, 1.0), fn=1, dinc=0, perturb=0.1,
                                 note="the headline on GENERAL quadrilaterals: interior nodes displaced by U(-0.1 h, 0.1 h) (the commented-out "
                                      "perturbation of convergence_test.cpp:176-187, numpy default_rng(12345)): no two cells are congruent, "
@@ -103,12 +107,12 @@ def cpu_baseline_cut(w, target_seconds=15.0):
     msh = oracle_lib.CutMesh(N, refsteps=4)
     di = oracle_lib.degrees(w["cd"], w["fd"])
     t0 = time.perf_counter()
-    cuthho_driver.oracle_cut_provider(msh, di)
+    (cuthho_driver.oracle_interface_provider if w.get("interface") else cuthho_driver.oracle_cut_provider)(msh, di)
     dt = time.perf_counter() - t0
     ncut = int((msh.cell_loc == oracle_lib.CUT_ON_INTERFACE).sum())
     return {"value": msh.nc / dt, "unit": "cells/s", "cores": 1, "kind": "port",
-            "sample": "%dx%d mesh of the same problem (%d cells, %d cut), %.1f s, oracle cut + uncut operators and rhs, single thread"
-                      % (N, N, msh.nc, ncut, dt)}
+            "sample": "%dx%d mesh of the same problem (%d cells, %d cut), %.1f s, oracle %s + uncut operators and rhs, single thread"
+                      % (N, N, msh.nc, ncut, dt, "two-sided (interface)" if w.get("interface") else "cut")}
 
 
 def perturbation(N, lo, hi, amount):
@@ -253,7 +257,11 @@ class Pipeline:
                 self.values = torch.empty(max(self.ainfo.nnz, 1), **f64)
                 self.b = torch.empty(max(self.ainfo.nrows, 1), **f64)
                 self.g = torch.empty((asm.assembler_info(w["cd"], w["fd"]).nfaces_local, sz.fbs), **f64)
-            if self.cut:
+            if self.cut and w.get("interface"):
+                self.iparms = pa.capi.InterfaceParams(*w["interface"])
+                self.cut_lc = torch.empty((max(asm.ncut, 1), 2 * sz.msize, 2 * sz.msize), **f64)
+                self.cut_rhs = torch.empty((max(asm.ncut, 1), 2 * sz.cbs), **f64)
+            elif self.cut:
                 self.cut_lc = torch.empty((max(asm.ncut, 1), sz.msize, sz.msize), **f64)
                 self.cut_rhs = torch.empty((max(asm.ncut, 1), sz.cbs), **f64)
         else:
@@ -289,6 +297,18 @@ class Pipeline:
         pa, asm, w, di, n = self.pa, self.asm, self.w, self.di, self.n
         if self.mode in ("L", "A"):
             self._tick(i, "start")
+            if self.cut and w.get("interface"):
+                # run_cuthho_interface's loop (cuthho_square.cpp:1666-1714): the cut cells' two-sided operators and right-hand sides
+                # (2 msize unknowns), then every cell's one-sided ones; the assembler takes the cut cells' from the first array
+                if asm.ncut:
+                    asm.ctx.cut_interface_ops(w["fd"], asm.level_set, self.iparms, w["fn"], None, None, self.cut_lc.data_ptr(),
+                                              self.cut_rhs.data_ptr(), None)
+                self._tick(i, "cut")
+                asm.ctx.cut_interface_uncut(w["fd"], self.iparms, w["fn"], self.lc.data_ptr(), None, None)
+                self._tick(i, "ops")
+                asm.ctx.cut_interface_uncut(w["fd"], self.iparms, w["fn"], None, self.rhs.data_ptr(), None)
+                self._tick(i, "rhs")
+                return
             if self.cut and asm.ncut:
                 asm.ctx.cut_local_ops(w["fd"], asm.level_set, pa.capi.LOC_NEGATIVE, w["fn"], 2, None, None, None,
                                       self.cut_lc.data_ptr(), self.cut_rhs.data_ptr(), None)
@@ -504,6 +524,8 @@ def main():
     mode = args.mode or ("L" if world == 1 else "C")
     w = WORKLOADS[workload]
     N = w["N"]
+    if w.get("interface") and mode != "L":
+        raise SystemExit("the interface workload runs in mode L (the two-sided cells have 2 msize unknowns: no condensed form is built)")
     if (w.get("cut") or w.get("perturb")) and mode == "A":
         raise SystemExit("mode A runs on the generator mesh (assembler<Mesh>'s system of a fictitious-domain problem drops the cells outside the domain: not built)")
     if mode == "A" and world > 1:

@@ -23,7 +23,7 @@ dominant = 0.0
 # kernel of the small pairs; with cut cells also their kernel and the merge); C -- every kernel of the step (cell rhs, operators with
 # the condensation fused, CSR fill)
 DOM = ["hho_local_ops_kernel", "hho_cell_pre_kernel", "hho_small_ops_kernel", "cut_local_ops_kernel", "cut_merge_cells_kernel", "cut_zero_rhs_kernel",
-       "cut_merge_condensed_kernel", "static_condensation_kernel"]
+       "cut_merge_condensed_kernel", "static_condensation_kernel", "cut_interface_kernel", "cut_interface_lc_kernel"]
 if mode == "C":
     DOM += ["cell_rhs_kernel", "cond_fill_kernel", "cond_rhs_rows_kernel"]
 STEP_KERNELS = DOM + ["cell_rhs_kernel", "cond_fill_kernel", "cond_rhs_rows_kernel", "asm_fill_cells_kernel", "asm_fill_faces_kernel", "dirichlet_data_kernel"]

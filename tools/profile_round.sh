@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 SPECS="$@"
-[ -z "$SPECS" ] && SPECS="quad1024_k2:L quad1024_k2:C quad1024_k2:A quad1024_k1:L quad1024_k1:C quad1024_k3:L quad1024_k3:C obstacle512_k1:L obstacle512_k1:C quad2048_k3:L quad2048_k3:C quad256_k1_fan:L quad512_k2_fan:L cuthho512_k2:L cuthho512_k2:C quad1024_k2_general:L quad1024_k2_general:C"
+[ -z "$SPECS" ] && SPECS="quad1024_k2:L quad1024_k2:C quad1024_k2:A quad1024_k1:L quad1024_k1:C quad1024_k3:L quad1024_k3:C obstacle512_k1:L obstacle512_k1:C quad2048_k3:L quad2048_k3:C quad256_k1_fan:L quad512_k2_fan:L cuthho512_k2:L cuthho512_k2:C cuthho512_k2_interface:L quad1024_k2_general:L quad1024_k2_general:C"
 for spec in $SPECS; do
   W=${spec%%:*}; M=${spec##*:}
   D=$OUT/${W}_$M
