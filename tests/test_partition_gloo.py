@@ -198,3 +198,69 @@ def test_slabs_with_halo_exchange_equal_the_whole_system(N, cd, fd, world):
         assert np.abs(br - b[row:row + Ar.shape[0]]).max() <= 1e-15 * max(1.0, np.abs(b).max())
         row += Ar.shape[0]
     assert row == info.system_size
+
+
+def _cut_worker(rank, world, port, N, k, q):
+    """One rank of the cut workload (config 3) under the row rule, the oracle standing in for the kernels: every rank runs the SAME
+    whole-mesh preprocessing (what pa_cut_preprocess_rows does on the host), keeps the cells of its rows, computes their merged local
+    matrices -- and the ranks' checksums meet in an all-reduce, as bench.py's `exchange_checked` of mode L does."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_lib as o
+        msh = o.CutMesh(N, refsteps=3)
+        di = o.degrees(k + 1, k)
+        r0, r1 = row_partition(N, world, rank)
+        mine = range(r0 * N, r1 * N)
+        cut = [c for c in mine if msh.cell_loc[c] == o.CUT_ON_INTERFACE]
+        sums = np.zeros(3)
+        for c in mine:
+            st, oper, data = msh.laplacian(c, di)
+            assert st == 0
+            st, stab = msh.cut_stabilization(c, di)
+            assert st == 0
+            lc = data + stab
+            sums += (lc.sum(), np.abs(lc).sum(), 1.0)
+        t = torch.from_numpy(sums.copy())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        counts = [None] * world
+        dist.all_gather_object(counts, cut)
+        q.put((rank, (sums, t.numpy().copy(), counts)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,k,world", [(10, 1, 2), (9, 0, 3)])
+def test_cut_cells_shard_by_the_same_row_rule(N, k, world):
+    """"cut cells (config 3) are distributed by the same row rule" -- the ranks' cut cells are disjoint, their union
+    is the whole mesh's, and the all-reduced checksums of the ranks' local matrices are those of one process."""
+    import oracle_lib as o
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cut_worker, args=(r, world, port, N, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    msh = o.CutMesh(N, refsteps=3)
+    di = o.degrees(k + 1, k)
+    all_cut = [c for c in range(msh.nc) if msh.cell_loc[c] == o.CUT_ON_INTERFACE]
+    ref = np.zeros(3)
+    for c in range(msh.nc):
+        st, oper, data = msh.laplacian(c, di)
+        st, stab = msh.cut_stabilization(c, di)
+        lc = data + stab
+        ref += (lc.sum(), np.abs(lc).sum(), 1.0)
+    gathered = results[0][2]
+    assert sorted(sum(gathered, [])) == all_cut and sum(len(g) for g in gathered) == len(all_cut) > 0
+    for r in range(world):
+        assert results[r][2] == gathered
+        tot = results[r][1]
+        assert tot[2] == msh.nc
+        assert abs(tot[0] - ref[0]) <= 1e-12 * ref[1] and abs(tot[1] - ref[1]) <= 1e-12 * ref[1]
